@@ -1,0 +1,280 @@
+"""ctypes binding of the flat C ABI in include/sf3d.h.
+
+The same `SF3D` class drives any of the three shared libraries that export the ABI:
+the HIP product (`libsf3d_hip.so`), the CPU restatement (`oracle/libsf3d_oracle.so`) and the
+wrapped, unmodified reference (`oracle/_ref/libsf3d_ref.so`).  This module is plumbing only:
+it holds no numerical code.  Product code paths must use `load_product()`, which raises if the
+HIP library is missing - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+PRODUCT_LIB = ROOT / "criteria3d_amd" / "csrc" / "libsf3d_hip.so"
+ORACLE_LIB = ROOT / "oracle" / "libsf3d_oracle.so"
+REFERENCE_LIB = ROOT / "oracle" / "_ref" / "libsf3d_ref.so"
+QT_CORE = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))
+
+# --- enums (include/sf3d.h) ---------------------------------------------------------------
+OK, INDEX_ERROR, MEMORY_ERROR, TOPOGRAPHY_ERROR, BOUNDARY_ERROR, MISSING_DATA_ERROR, \
+    PARAMETER_ERROR, SOLVER_ERROR, FILE_ERROR = range(9)
+BND_NONE, BND_RUNOFF, BND_FREE_DRAINAGE, BND_FREE_LATERAL_DRAINAGE, BND_PRESCRIBED, BND_URBAN, \
+    BND_ROAD, BND_CULVERT, BND_HEAT_SURFACE, BND_SOLUTE_FLUX = range(10)
+LINK_NONE, LINK_UP, LINK_DOWN, LINK_LATERAL = range(4)
+WRC_VG, WRC_MODIFIED_VG, WRC_CAMPBELL = range(3)
+MEAN_ARITHMETIC, MEAN_GEOMETRIC, MEAN_LOGARITHMIC = range(3)
+
+ERROR_NAMES = ["ok", "index error", "memory error", "topography error", "boundary error",
+               "missing data error", "parameter error", "solver error", "file error"]
+
+u8, u16, u32, u64 = C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64
+f64, f32, i32 = C.c_double, C.c_float, C.c_int
+pd = C.POINTER(C.c_double)
+p8, p16, p32, p64 = C.POINTER(u8), C.POINTER(u16), C.POINTER(u32), C.POINTER(u64)
+cstr, vp = C.c_char_p, C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/sf3d.h declares
+SIGNATURES = {
+    "sf3d_initialize": (u8, [u32, u32, u8, i32, i32, i32, u8]),
+    "sf3d_initialize_balance": (u8, []),
+    "sf3d_initialize_log": (u8, [cstr, cstr]),
+    "sf3d_clean": (u8, []),
+    "sf3d_close_log": (u8, []),
+    "sf3d_initialize_heat_flag": (u8, [u8, i32, i32]),
+    "sf3d_set_threads_number": (u32, [u32]),
+    "sf3d_set_use_lineal": (None, [i32]),
+    "sf3d_set_lineal_method": (None, [i32]),
+    "sf3d_set_soil_properties": (u8, [u16, u8] + [f64] * 10),
+    "sf3d_set_surface_properties": (u8, [u16, f64]),
+    "sf3d_set_numerical_parameters": (u8, [f64, f64, u16, u16, u8, u8]),
+    "sf3d_set_hydraulic_properties": (u8, [u8, u8, f32]),
+    "sf3d_set_culvert": (u8, [u32, f64, f64, f64, f64]),
+    "sf3d_set_node": (u8, [u32, f64, f64, f64, f64, i32, u8, f64, f64]),
+    "sf3d_set_node_link": (u8, [u32, u32, u8, f64]),
+    "sf3d_set_node_boundary": (u8, [u32, u8, f64, f64]),
+    "sf3d_set_node_soil": (u8, [u32, u16, u16]),
+    "sf3d_set_node_surface": (u8, [u32, u16]),
+    "sf3d_set_node_pond": (u8, [u32, f64]),
+    "sf3d_set_node_water_content": (u8, [u32, f64]),
+    "sf3d_set_node_degree_of_saturation": (u8, [u32, f64]),
+    "sf3d_set_node_matric_potential": (u8, [u32, f64]),
+    "sf3d_set_node_total_potential": (u8, [u32, f64]),
+    "sf3d_set_node_water_sink_source": (u8, [u32, f64]),
+    "sf3d_set_node_prescribed_total_potential": (u8, [u32, f64]),
+    "sf3d_get_node_water_content": (f64, [u32]),
+    "sf3d_get_node_maximum_water_content": (f64, [u32]),
+    "sf3d_get_node_minimum_water_content": (f64, [u32]),
+    "sf3d_get_node_available_water_content": (f64, [u32]),
+    "sf3d_get_node_water_deficit": (f64, [u32, f64]),
+    "sf3d_get_node_degree_of_saturation": (f64, [u32]),
+    "sf3d_get_node_water_conductivity": (f64, [u32]),
+    "sf3d_get_node_matric_potential": (f64, [u32]),
+    "sf3d_get_node_total_potential": (f64, [u32]),
+    "sf3d_get_node_pond": (f64, [u32]),
+    "sf3d_get_node_max_water_flow": (f64, [u32, u8]),
+    "sf3d_get_node_sum_lateral_water_flow": (f64, [u32]),
+    "sf3d_get_node_sum_lateral_water_flow_in": (f64, [u32]),
+    "sf3d_get_node_sum_lateral_water_flow_out": (f64, [u32]),
+    "sf3d_get_node_boundary_water_flow": (f64, [u32]),
+    "sf3d_get_total_boundary_water_flow": (f64, [u8]),
+    "sf3d_get_total_water_content": (f64, []),
+    "sf3d_get_water_storage": (f64, []),
+    "sf3d_get_water_mbr": (f64, []),
+    "sf3d_set_node_heat_sink_source": (u8, [u32, f64]),
+    "sf3d_set_node_temperature": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_fixed_temperature": (u8, [u32, f64, f64]),
+    "sf3d_set_node_boundary_height_wind": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_height_temperature": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_net_irradiance": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_temperature": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_relative_humidity": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_roughness": (u8, [u32, f64]),
+    "sf3d_set_node_boundary_wind_speed": (u8, [u32, f64]),
+    "sf3d_get_node_temperature": (f64, [u32]),
+    "sf3d_get_node_heat_conductivity": (f64, [u32]),
+    "sf3d_get_node_vapor": (f64, [u32]),
+    "sf3d_get_node_heat_storage": (f64, [u32, f64]),
+    "sf3d_get_node_heat_max_flux": (f64, [u32, u8, u8]),
+    "sf3d_get_node_boundary_advective_flux": (f64, [u32]),
+    "sf3d_get_node_boundary_latent_flux": (f64, [u32]),
+    "sf3d_get_node_boundary_radiative_flux": (f64, [u32]),
+    "sf3d_get_node_boundary_sensible_flux": (f64, [u32]),
+    "sf3d_get_node_boundary_aerodynamic_conductance": (f64, [u32]),
+    "sf3d_get_node_boundary_soil_conductance": (f64, [u32]),
+    "sf3d_get_heat_mbr": (f64, []),
+    "sf3d_get_heat_mbe": (f64, []),
+    "sf3d_compute_period": (None, [f64]),
+    "sf3d_compute_step": (f64, [f64]),
+    # extensions
+    "sf3d_backend_name": (cstr, []),
+    "sf3d_set_nodes": (u8, [u32, u32, pd, pd, pd, pd, p8, p8, pd, pd]),
+    "sf3d_set_node_links": (u8, [u64, p32, p32, p8, pd]),
+    "sf3d_set_nodes_soil": (u8, [u32, u32, p16, p16]),
+    "sf3d_set_nodes_surface": (u8, [u32, u32, p16]),
+    "sf3d_set_nodes_pond": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_matric_potential": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_total_potential": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_water_sink_source": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_total_potential": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_degree_of_saturation": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_water_content": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_water_conductivity": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_boundary_water_flow": (u8, [u32, u32, pd]),
+    "sf3d_get_counters": (u8, [p64]),
+    "sf3d_get_time_step": (f64, []),
+    "sf3d_reset_time_step": (u8, []),
+    "sf3d_set_device": (u8, [i32]),
+    "sf3d_synchronize": (u8, []),
+    "sf3d_kernel_timing": (u8, [i32]),
+    "sf3d_kernel_count": (i32, []),
+    "sf3d_kernel_name": (cstr, [i32]),
+    "sf3d_kernel_stats": (u8, [i32, p64, pd, p64]),
+}
+
+# the 70 entry points that stand in for soilFluxes3D.h:9-104 (everything before "extensions")
+REFERENCE_API = [k for k in SIGNATURES if k != "sf3d_backend_name"][:70]
+
+COUNTER_NAMES = ["attempts", "accepted", "approximations", "sweeps", "courant_rejections",
+                 "linear_failures", "restores", "reserved"]
+
+
+class SF3DError(RuntimeError):
+    pass
+
+
+def _arr(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a, ctype):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+class SF3D:
+    """One loaded implementation of the sf3d C ABI (process-global model inside the library)."""
+
+    def __init__(self, path: os.PathLike):
+        path = Path(path)
+        if not path.exists():
+            raise SF3DError(f"shared library not found: {path}")
+        self.path = path
+        self.lib = C.CDLL(str(path), mode=C.RTLD_LOCAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.lib, name)        # AttributeError = symbol missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        self.backend = self.lib.sf3d_backend_name().decode()
+
+    # -- helpers -------------------------------------------------------------------------
+    def check(self, code: int, what: str = ""):
+        if code != OK:
+            raise SF3DError(f"{self.backend}: {what}: {ERROR_NAMES[code] if code < 9 else code}")
+
+    def __getattr__(self, name):
+        # raw access: obj.set_node(...) -> lib.sf3d_set_node(...)
+        try:
+            return getattr(self.__dict__["lib"], "sf3d_" + name)
+        except (KeyError, AttributeError):
+            raise AttributeError(name)
+
+    # -- bulk helpers over numpy arrays ----------------------------------------------------
+    def set_nodes_bulk(self, first, x, y, z, size, is_surface, btype, slope, barea):
+        n = len(x)
+        x, y, z, size = (_arr(a, np.float64) for a in (x, y, z, size))
+        is_surface, btype = _arr(is_surface, np.uint8), _arr(btype, np.uint8)
+        slope, barea = _arr(slope, np.float64), _arr(barea, np.float64)
+        self.check(self.lib.sf3d_set_nodes(first, n, _ptr(x, f64), _ptr(y, f64), _ptr(z, f64),
+                                           _ptr(size, f64), _ptr(is_surface, u8), _ptr(btype, u8),
+                                           _ptr(slope, f64), _ptr(barea, f64)), "set_nodes")
+
+    def set_links_bulk(self, node, linked, direction, area):
+        node, linked = _arr(node, np.uint32), _arr(linked, np.uint32)
+        direction, area = _arr(direction, np.uint8), _arr(area, np.float64)
+        self.check(self.lib.sf3d_set_node_links(len(node), _ptr(node, u32), _ptr(linked, u32),
+                                                _ptr(direction, u8), _ptr(area, f64)), "set_node_links")
+
+    def set_soil_bulk(self, first, soil, horizon):
+        soil, horizon = _arr(soil, np.uint16), _arr(horizon, np.uint16)
+        self.check(self.lib.sf3d_set_nodes_soil(first, len(soil), _ptr(soil, u16), _ptr(horizon, u16)), "set_nodes_soil")
+
+    def set_surface_bulk(self, first, surf):
+        surf = _arr(surf, np.uint16)
+        self.check(self.lib.sf3d_set_nodes_surface(first, len(surf), _ptr(surf, u16)), "set_nodes_surface")
+
+    def _set_f64(self, fn, first, v, what):
+        v = _arr(v, np.float64)
+        self.check(fn(first, len(v), _ptr(v, f64)), what)
+
+    def set_pond_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_pond, first, v, "set_nodes_pond")
+
+    def set_matric_potential_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_matric_potential, first, v, "set_nodes_matric_potential")
+
+    def set_total_potential_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_total_potential, first, v, "set_nodes_total_potential")
+
+    def set_sink_source_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_water_sink_source, first, v, "set_nodes_water_sink_source")
+
+    def _get_f64(self, fn, first, count, what):
+        out = np.empty(count, dtype=np.float64)
+        self.check(fn(first, count, _ptr(out, f64)), what)
+        return out
+
+    def total_potential(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_total_potential, first, count, "get_nodes_total_potential")
+
+    def degree_of_saturation(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_degree_of_saturation, first, count, "get_nodes_degree_of_saturation")
+
+    def water_content(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_water_content, first, count, "get_nodes_water_content")
+
+    def water_conductivity(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_water_conductivity, first, count, "get_nodes_water_conductivity")
+
+    def boundary_water_flow(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_boundary_water_flow, first, count, "get_nodes_boundary_water_flow")
+
+    def counters(self):
+        out = (u64 * 8)()
+        code = self.lib.sf3d_get_counters(out)
+        if code != OK:
+            return None
+        return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def kernel_stats(self):
+        """{kernel name: (launches, total_ms, nodes_per_launch)} from the HIP-event pool."""
+        res = {}
+        for k in range(self.lib.sf3d_kernel_count()):
+            n, ms, npl = u64(0), f64(0.0), u64(0)
+            self.check(self.lib.sf3d_kernel_stats(k, C.byref(n), C.byref(ms), C.byref(npl)), "kernel_stats")
+            res[self.lib.sf3d_kernel_name(k).decode()] = (int(n.value), float(ms.value), int(npl.value))
+        return res
+
+
+def load_product() -> SF3D:
+    """The HIP/gfx950 product library.  Raises (never falls back) if it has not been built."""
+    if not PRODUCT_LIB.exists():
+        raise SF3DError(f"{PRODUCT_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                        "there is no CPU fallback for the product path")
+    return SF3D(PRODUCT_LIB)
+
+
+def load_oracle() -> SF3D:
+    """CPU restatement (TEST INFRASTRUCTURE: tests/, smoke(), bench cpu_baseline only)."""
+    return SF3D(ORACLE_LIB)
+
+
+def load_reference() -> SF3D:
+    """The wrapped, unmodified reference (TEST INFRASTRUCTURE; built by oracle/Makefile `ref`)."""
+    if QT_CORE.exists():
+        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)   # linked by soname, deliberately not on the rpath
+    return SF3D(REFERENCE_LIB)

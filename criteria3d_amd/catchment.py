@@ -1,0 +1,237 @@
+"""Synthetic model builders and scenario runner for the sf3d C ABI (host-side harness).
+
+The graph-construction rules restate what the reference's caller does
+(src/project3D/project3D.cpp:941-1103 `setCrit3DTopography`):
+layer-major / row-major node numbering with the surface layer first, Up/Down links with the
+cell area, eight lateral links per node in the (row, col) offset order
+(-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1) with interface area 0.5*lateralArea,
+Runoff / FreeLateralDrainage on the outlet edge and FreeDrainage under the last layer.
+All calls go through the public ABI, so the same builder feeds the reference, the CPU
+restatement and the HIP product.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+# loam-like soil used by SURVEY.md 8c/8d (alpha [1/m], n, he [m], thetaR, thetaS, Ksat [m/s], L)
+LOAM = dict(alpha=3.6, n=1.56, he=0.1, theta_r=0.078, theta_s=0.43, ksat=2.9e-6, L=0.5,
+            organic_matter=0.01, clay=0.2)
+
+# van_genuchten table of DATA/PROJECT/Ravone/SOIL/soil_ER_2021.db:
+# texture, alpha [1/kPa], n, he [kPa], thetaR, thetaS, Ksat [cm/d], L
+USDA_VG = [
+    ("sand", 0.40, 1.70, 0.7, 0.01, 0.38, 192.0, 0.5), ("loamy sand", 0.35, 1.50, 1.0, 0.02, 0.39, 96.0, 0.5),
+    ("sandy loam", 0.29, 1.35, 1.5, 0.03, 0.40, 48.0, 0.5), ("silt loam", 0.14, 1.25, 2.6, 0.03, 0.44, 4.8, 0.5),
+    ("loam", 0.16, 1.25, 2.3, 0.03, 0.43, 9.6, 0.5), ("silt", 0.10, 1.24, 2.7, 0.03, 0.44, 2.4, 0.5),
+    ("sandy clayloam", 0.22, 1.24, 2.1, 0.03, 0.42, 12.0, 0.5), ("silty clayloam", 0.13, 1.22, 3.1, 0.03, 0.46, 2.4, 0.5),
+    ("clayloam", 0.18, 1.19, 2.7, 0.04, 0.45, 3.6, 0.5), ("sandy clay", 0.21, 1.20, 2.5, 0.04, 0.44, 4.8, 0.5),
+    ("silty clay", 0.17, 1.19, 3.3, 0.05, 0.48, 2.4, 0.5), ("clay", 0.16, 1.18, 3.7, 0.05, 0.49, 1.2, 0.5),
+]
+GRAVITY = 9.80665
+
+LATERAL_OFFSETS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
+
+
+@dataclass
+class Model:
+    """Arrays describing one model, ready to be pushed through the ABI."""
+    n: int
+    ns: int
+    x: np.ndarray
+    y: np.ndarray
+    z: np.ndarray
+    size: np.ndarray
+    is_surface: np.ndarray
+    btype: np.ndarray
+    bslope: np.ndarray
+    barea: np.ndarray
+    link_node: np.ndarray
+    link_to: np.ndarray
+    link_dir: np.ndarray
+    link_area: np.ndarray
+    soil_index: np.ndarray            # per soil node (n - ns): index into `soils`
+    soils: list                        # list of dicts (LOAM-like keys)
+    roughness: float = 0.05
+    pond: float = 0.002
+    psi0_surface: float = 0.0
+    psi0_soil: float = -2.0
+    lv_ratio: float = 10.0
+    numerics: tuple = (0.5, 3600.0, 150, 10, 10, 3)
+    cell_area: float = 100.0
+    shape: tuple = ()
+    meta: dict = field(default_factory=dict)
+
+
+def splitmix64(v: np.ndarray) -> np.ndarray:
+    v = (v + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    v = (v ^ (v >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    v = (v ^ (v >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return v ^ (v >> np.uint64(31))
+
+
+def usda_soils():
+    """The 12 USDA classes converted as the caller does (project3D.cpp:915-925)."""
+    out = []
+    for _, a, n, he, tr, ts, ks, L in USDA_VG:
+        out.append(dict(alpha=a * GRAVITY, n=n, he=he / GRAVITY, theta_r=tr, theta_s=ts,
+                        ksat=ks * 0.01 / 86400.0, L=L, organic_matter=0.01, clay=0.2))
+    return out
+
+
+def column_model(n_nodes: int = 100, dz: float = 0.02, area: float = 1.0) -> Model:
+    """C1 of SURVEY.md 8c: node 0 surface, 99 soil nodes, FreeDrainage bottom."""
+    n = n_nodes
+    i = np.arange(n)
+    z = np.where(i == 0, 0.0, -(dz * (i - 0.5)))
+    size = np.where(i == 0, area, area * dz)
+    btype = np.zeros(n, np.uint8)
+    btype[n - 1] = capi.BND_FREE_DRAINAGE
+    barea = np.zeros(n)
+    barea[n - 1] = area
+    ln, lt, ld = [], [], []
+    for k in range(n):
+        if k > 0:
+            ln.append(k); lt.append(k - 1); ld.append(capi.LINK_UP)
+        if k < n - 1:
+            ln.append(k); lt.append(k + 1); ld.append(capi.LINK_DOWN)
+    return Model(n=n, ns=1, x=np.zeros(n), y=np.zeros(n), z=z, size=size,
+                 is_surface=(i == 0).astype(np.uint8), btype=btype, bslope=np.zeros(n), barea=barea,
+                 link_node=np.array(ln, np.uint32), link_to=np.array(lt, np.uint32),
+                 link_dir=np.array(ld, np.uint8), link_area=np.full(len(ln), area),
+                 soil_index=np.zeros(n - 1, np.uint16), soils=[LOAM], psi0_soil=-3.0,
+                 numerics=(1.0, 3600.0, 150, 10, 10, 3), cell_area=area, shape=(1, 1, n),
+                 meta=dict(kind="column"))
+
+
+def catchment_model(nx: int, ny: int, nz: int, heterogeneous: bool = False, cell: float = 10.0,
+                    thickness: float = 0.10) -> Model:
+    """Tilted-plane catchment of SURVEY.md 8d (C2-C4).  nz counts the surface layer."""
+    ns, n = nx * ny, nx * ny * nz
+    area = cell * cell
+    l, r, c = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    l, r, c = l.ravel(), r.ravel(), c.ravel()
+    x, y = c * cell, r * cell
+    zs = 100.0 + 0.05 * x + 0.02 * y
+    depth = 0.05 + 0.1 * (l - 1)
+    z = np.where(l == 0, zs, zs - depth)
+    size = np.where(l == 0, area, area * thickness)
+    outlet = (r == 0) | (c == 0)
+    slope = 0.0538
+    btype = np.zeros(n, np.uint8)
+    bslope = np.zeros(n)
+    barea = np.zeros(n)
+    surf_out = (l == 0) & outlet
+    btype[surf_out] = capi.BND_RUNOFF; bslope[surf_out] = slope; barea[surf_out] = cell
+    lat_out = (l > 0) & outlet
+    btype[lat_out] = capi.BND_FREE_LATERAL_DRAINAGE; bslope[lat_out] = slope; barea[lat_out] = cell * thickness
+    bottom = (l == nz - 1) & (nz > 1)
+    btype[bottom] = capi.BND_FREE_DRAINAGE; bslope[bottom] = 0.0; barea[bottom] = area
+
+    idx = np.arange(n, dtype=np.int64)
+    # candidate links per node in call order: Up, Down, 8 laterals
+    cand_to = np.full((n, 10), -1, dtype=np.int64)
+    cand_dir = np.zeros((n, 10), np.uint8)
+    cand_area = np.zeros((n, 10))
+    up = l > 0
+    cand_to[up, 0] = idx[up] - ns; cand_dir[:, 0] = capi.LINK_UP; cand_area[:, 0] = area
+    dn = l < nz - 1
+    cand_to[dn, 1] = idx[dn] + ns; cand_dir[:, 1] = capi.LINK_DOWN; cand_area[:, 1] = area
+    lat_area = np.where(l == 0, cell, cell * thickness) * 0.5
+    for k, (dr, dc) in enumerate(LATERAL_OFFSETS):
+        rr, cc = r + dr, c + dc
+        ok = (rr >= 0) & (rr < ny) & (cc >= 0) & (cc < nx)
+        cand_to[ok, 2 + k] = (l[ok] * ny + rr[ok]) * nx + cc[ok]
+        cand_dir[:, 2 + k] = capi.LINK_LATERAL
+        cand_area[:, 2 + k] = lat_area
+    mask = cand_to >= 0
+    link_node = np.broadcast_to(idx[:, None], (n, 10))[mask].astype(np.uint32)
+    link_to = cand_to[mask].astype(np.uint32)
+    link_dir = cand_dir[mask]
+    link_area = cand_area[mask]
+
+    if heterogeneous:
+        soils = usda_soils()
+        rs, cs = r[ns:] // 8, c[ns:] // 8
+        h = splitmix64(np.uint64(1234) ^ (rs.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ cs.astype(np.uint64))
+        soil_index = (h % np.uint64(12)).astype(np.uint16)
+    else:
+        soils = [LOAM]
+        soil_index = np.zeros(n - ns, np.uint16)
+    return Model(n=n, ns=ns, x=x.astype(float), y=y.astype(float), z=z, size=size,
+                 is_surface=(l == 0).astype(np.uint8), btype=btype, bslope=bslope, barea=barea,
+                 link_node=link_node, link_to=link_to, link_dir=link_dir, link_area=link_area,
+                 soil_index=soil_index, soils=soils, numerics=(min(6.0, cell / 20.0), 3600.0, 150, 10, 10, 3),
+                 cell_area=area, shape=(nx, ny, nz), meta=dict(kind="catchment", heterogeneous=heterogeneous))
+
+
+def build(sf: capi.SF3D, m: Model, threads: int = 1):
+    """Push a Model through the ABI in the caller's order."""
+    sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
+    sf.check(sf.lib.sf3d_set_surface_properties(0, m.roughness), "set_surface_properties")
+    for k, s in enumerate(m.soils):
+        # soil number k+? : the catchment uses (soil=k, horizon=0)
+        sf.check(sf.lib.sf3d_set_soil_properties(k, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"],
+                                                 s["theta_r"], s["theta_s"], s["ksat"], s["L"],
+                                                 s["organic_matter"], s["clay"]), "set_soil_properties")
+    sf.set_nodes_bulk(0, m.x, m.y, m.z, m.size, m.is_surface, m.btype, m.bslope, m.barea)
+    sf.set_links_bulk(m.link_node, m.link_to, m.link_dir, m.link_area)
+    sf.set_surface_bulk(0, np.zeros(m.ns, np.uint16))
+    sf.set_pond_bulk(0, np.full(m.ns, m.pond))
+    if m.n > m.ns:
+        sf.set_soil_bulk(m.ns, m.soil_index, np.zeros(m.n - m.ns, np.uint16))
+    sf.check(sf.lib.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, m.lv_ratio),
+             "set_hydraulic_properties")
+    sf.check(sf.lib.sf3d_set_numerical_parameters(*m.numerics), "set_numerical_parameters")
+    sf.lib.sf3d_set_threads_number(threads)
+    psi = np.full(m.n, m.psi0_soil)
+    psi[:m.ns] = m.psi0_surface
+    sf.set_matric_potential_bulk(0, psi)
+    sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
+
+
+def rain_rate(mm_per_hour: float, cell_area: float) -> float:
+    """surface source [m3/s] per cell, as assignPrecipitation does (criteria3DProject.cpp:914-968)."""
+    return mm_per_hour * 1e-3 / 3600.0 * cell_area
+
+
+FORCINGS = {
+    "F20": lambda h: 20.0 if h == 0 else 0.0,      # infiltration regime
+    "F60": lambda h: 60.0 if h == 0 else 0.0,      # runoff regime
+    "R5": lambda h: 5.0,                            # C1: constant 5 mm/h
+}
+
+
+def run_hour(sf: capi.SF3D, m: Model, mm: float, use_period: bool = False, max_steps: int | None = None):
+    """One simulated hour: hourly sinks then the caller's computeStep loop
+    (project3D.cpp:1330-1359).  Returns (steps, list of accepted dt)."""
+    sf.set_sink_source_bulk(0, np.full(m.ns, rain_rate(mm, m.cell_area)))
+    if use_period:
+        sf.lib.sf3d_compute_period(3600.0)
+        return None, None
+    t, dts = 0.0, []
+    while t < 3600.0:
+        dt = sf.lib.sf3d_compute_step(3600.0 - t)
+        if not (dt > 0.0):
+            raise capi.SF3DError(f"{sf.backend}: compute_step returned {dt}")
+        dts.append(dt)
+        t += dt
+        if max_steps is not None and len(dts) >= max_steps:
+            break
+    return len(dts), dts
+
+
+def snapshot(sf: capi.SF3D, m: Model) -> dict:
+    return dict(
+        H=sf.total_potential(0, m.n),
+        Se=sf.degree_of_saturation(0, m.n),
+        total_water=sf.lib.sf3d_get_total_water_content(),
+        storage=sf.lib.sf3d_get_water_storage(),
+        mbr=sf.lib.sf3d_get_water_mbr(),
+        runoff=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_RUNOFF),
+        drainage=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_DRAINAGE),
+        lateral=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_LATERAL_DRAINAGE),
+    )

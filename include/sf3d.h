@@ -1,0 +1,329 @@
+/*
+ * sf3d.h - flat C ABI of the MI355X-native soilFluxes3D time-step library.
+ *
+ * This is the drop-in boundary.  Every entry point below replaces one
+ * function of the reference's public API `namespace soilFluxes3D::v2`
+ * (agrolib/soilFluxes3D/soilFluxes3D.h:9-104); the citation after each prototype is the
+ * reference declaration (header line) and definition (soilFluxes3D.cpp line) it stands in
+ * for.  Argument order, meaning, units, validation rules and return/sentinel values are the
+ * reference's.  Only plain scalars and caller-owned arrays cross the boundary; the library
+ * owns all solver memory.  One process-global model instance, not re-entrant (as the
+ * reference).
+ *
+ * Three shared libraries export this same ABI:
+ *   criteria3d_amd/csrc/libsf3d_hip.so   the product: HIP/gfx950 kernels (no CPU fallback)
+ *   oracle/libsf3d_oracle.so              CPU restatement of the reference algorithm (tests only)
+ *   oracle/_ref/libsf3d_ref.so            the unmodified reference sources behind a thin
+ *                                         forwarding wrapper (tests / cpu_baseline only)
+ *
+ * `shim/sf3d_cxx_shim.cpp` re-exports the product under the reference's 70 C++ mangled
+ * names so bin/CRITERIA3D links it unchanged.
+ */
+#ifndef SF3D_H
+#define SF3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (all uint8-backed, values identical to types.h) ------------------------- */
+
+/* SF3Derror_t, types.h:39-40 */
+typedef uint8_t sf3d_error_t;
+enum {
+    SF3D_OK = 0, SF3D_INDEX_ERROR = 1, SF3D_MEMORY_ERROR = 2, SF3D_TOPOGRAPHY_ERROR = 3,
+    SF3D_BOUNDARY_ERROR = 4, SF3D_MISSING_DATA_ERROR = 5, SF3D_PARAMETER_ERROR = 6,
+    SF3D_SOLVER_ERROR = 7, SF3D_FILE_ERROR = 8
+};
+
+/* boundaryType_t, types.h:98-99 */
+typedef uint8_t sf3d_boundary_t;
+enum {
+    SF3D_BND_NONE = 0, SF3D_BND_RUNOFF = 1, SF3D_BND_FREE_DRAINAGE = 2,
+    SF3D_BND_FREE_LATERAL_DRAINAGE = 3, SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL = 4,
+    SF3D_BND_URBAN = 5, SF3D_BND_ROAD = 6, SF3D_BND_CULVERT = 7, SF3D_BND_HEAT_SURFACE = 8,
+    SF3D_BND_SOLUTE_FLUX = 9
+};
+
+/* linkType_t, types.h:101 */
+typedef uint8_t sf3d_link_t;
+enum { SF3D_LINK_NONE = 0, SF3D_LINK_UP = 1, SF3D_LINK_DOWN = 2, SF3D_LINK_LATERAL = 3 };
+
+/* WRCModel, types.h:135 */
+typedef uint8_t sf3d_wrc_t;
+enum { SF3D_WRC_VAN_GENUCHTEN = 0, SF3D_WRC_MODIFIED_VAN_GENUCHTEN = 1, SF3D_WRC_CAMPBELL = 2 };
+
+/* meanType_t, types.h:36 */
+typedef uint8_t sf3d_mean_t;
+enum { SF3D_MEAN_ARITHMETIC = 0, SF3D_MEAN_GEOMETRIC = 1, SF3D_MEAN_LOGARITHMIC = 2 };
+
+/* heatFluxSaveMode_t, types.h:186 ; fluxTypes_t, types.h:199 */
+typedef uint8_t sf3d_heat_save_t;   /* 0 None, 1 Total, 2 All */
+typedef uint8_t sf3d_flux_t;        /* 0 HeatTotal ... 8 WaterVaporThermal */
+
+/* getter sentinels, types.h:42-64 + commonConstants.h:95-100 */
+#define SF3D_VAL_INDEX_ERROR        (-1111.0)
+#define SF3D_VAL_MEMORY_ERROR       (-2222.0)
+#define SF3D_VAL_TOPOGRAPHY_ERROR   (-3333.0)
+#define SF3D_VAL_BOUNDARY_ERROR     (-4444.0)
+#define SF3D_VAL_MISSING_DATA_ERROR (-9999.0)
+#define SF3D_VAL_PARAMETER_ERROR    (-7777.0)
+#define SF3D_NODATA                 (-9999.0)
+
+/* ---- initialisation and memory ------------------------------------------------------ */
+
+/* initializeSF3D            soilFluxes3D.h:9   soilFluxes3D.cpp:49-178 */
+sf3d_error_t sf3d_initialize(uint32_t nrNodes, uint32_t nrSurfaceNodes, uint8_t nrLateralLinks,
+                             int isComputeWater, int isComputeHeat, int isComputeSolutes,
+                             sf3d_heat_save_t heatSaveMode);
+/* initializeBalance         soilFluxes3D.h:13  soilFluxes3D.cpp:184-197, water.cpp:35-65 */
+sf3d_error_t sf3d_initialize_balance(void);
+/* initializeLog             soilFluxes3D.h:14  soilFluxes3D.cpp:203-212 (no-op unless MCR) */
+sf3d_error_t sf3d_initialize_log(const char* logPath, const char* projectName);
+/* cleanSF3D                 soilFluxes3D.h:16  soilFluxes3D.cpp:218-304 */
+sf3d_error_t sf3d_clean(void);
+/* closeLog                  soilFluxes3D.h:17  soilFluxes3D.cpp:310-319 */
+sf3d_error_t sf3d_close_log(void);
+/* initializeHeatFlag        soilFluxes3D.h:19  soilFluxes3D.cpp:325-332 */
+sf3d_error_t sf3d_initialize_heat_flag(sf3d_heat_save_t saveMode, int computeAdvectiveFlux,
+                                       int computeLatentHeat);
+/* setThreadsNumber          soilFluxes3D.h:21  soilFluxes3D.cpp:340-361 */
+uint32_t sf3d_set_threads_number(uint32_t nrThreads);
+/* setUseLineal              soilFluxes3D.h:22  soilFluxes3D.cpp:367-371 */
+void sf3d_set_use_lineal(int value);
+/* setLinealMethod           soilFluxes3D.h:23  soilFluxes3D.cpp:376-380 */
+void sf3d_set_lineal_method(int value);
+
+/* ---- soil / surface classes ---------------------------------------------------------- */
+
+/* setSoilProperties         soilFluxes3D.h:26-28  soilFluxes3D.cpp:395-449 */
+sf3d_error_t sf3d_set_soil_properties(uint16_t nrSoil, uint8_t nrHorizon, double VG_alpha,
+                                      double VG_n, double VG_m, double VG_he, double thetaR,
+                                      double thetaS, double kSat, double MualemL,
+                                      double organicMatter, double clay);
+/* setSurfaceProperties      soilFluxes3D.h:29  soilFluxes3D.cpp:457-467 */
+sf3d_error_t sf3d_set_surface_properties(uint16_t surfaceIndex, double roughness);
+
+/* ---- solver parameters ---------------------------------------------------------------- */
+
+/* setNumericalParameters    soilFluxes3D.h:32  soilFluxes3D.cpp:474-520 */
+sf3d_error_t sf3d_set_numerical_parameters(double minDeltaT, double maxDeltaT,
+                                           uint16_t maxIterationNumber,
+                                           uint16_t maxApproximationsNumber,
+                                           uint8_t residualToleranceExponent,
+                                           uint8_t MBRThresholdExponent);
+/* setHydraulicProperties    soilFluxes3D.h:33  soilFluxes3D.cpp:531-548 */
+sf3d_error_t sf3d_set_hydraulic_properties(sf3d_wrc_t waterRetentionCurve,
+                                           sf3d_mean_t conductivityMeanType,
+                                           float conductivityHorizVertRatio);
+
+/* ---- topology -------------------------------------------------------------------------- */
+
+/* setCulvert                soilFluxes3D.h:36  soilFluxes3D.cpp:551-588
+ * (the reference dereferences a never-allocated array here; this ABI returns
+ *  SF3D_BOUNDARY_ERROR = "unsupported") */
+sf3d_error_t sf3d_set_culvert(uint32_t nodeIndex, double roughness, double slope, double width,
+                              double height);
+/* setNode                   soilFluxes3D.h:37  soilFluxes3D.cpp:595-629 */
+sf3d_error_t sf3d_set_node(uint32_t index, double x, double y, double z, double volume_or_area,
+                           int isSurface, sf3d_boundary_t boundaryType, double slope,
+                           double boundaryArea);
+/* setNodeLink               soilFluxes3D.h:38  soilFluxes3D.cpp:636-683 */
+sf3d_error_t sf3d_set_node_link(uint32_t nodeIndex, uint32_t linkIndex, sf3d_link_t direction,
+                                double interfaceArea);
+/* setNodeBoundary           soilFluxes3D.h:39  soilFluxes3D.cpp:689-725 */
+sf3d_error_t sf3d_set_node_boundary(uint32_t nodeIndex, sf3d_boundary_t boundaryType,
+                                    double slope, double boundaryArea);
+/* setNodeSoil               soilFluxes3D.h:42  soilFluxes3D.cpp:734-750 */
+sf3d_error_t sf3d_set_node_soil(uint32_t nodeIndex, uint16_t soilIndex, uint16_t horizonIndex);
+/* setNodeSurface            soilFluxes3D.h:43  soilFluxes3D.cpp:758-775 */
+sf3d_error_t sf3d_set_node_surface(uint32_t nodeIndex, uint16_t surfaceIndex);
+
+/* ---- water state setters --------------------------------------------------------------- */
+
+/* setNodePond               soilFluxes3D.h:46  soilFluxes3D.cpp:783-796 */
+sf3d_error_t sf3d_set_node_pond(uint32_t nodeIndex, double pond);
+/* setNodeWaterContent       soilFluxes3D.h:47  soilFluxes3D.cpp:803-835 */
+sf3d_error_t sf3d_set_node_water_content(uint32_t nodeIndex, double waterContent);
+/* setNodeDegreeOfSaturation soilFluxes3D.h:48  soilFluxes3D.cpp:842-862 */
+sf3d_error_t sf3d_set_node_degree_of_saturation(uint32_t nodeIndex, double degreeOfSaturation);
+/* setNodeMatricPotential    soilFluxes3D.h:49  soilFluxes3D.cpp:869-884 */
+sf3d_error_t sf3d_set_node_matric_potential(uint32_t nodeIndex, double matricPotential);
+/* setNodeTotalPotential     soilFluxes3D.h:50  soilFluxes3D.cpp:891-906 */
+sf3d_error_t sf3d_set_node_total_potential(uint32_t nodeIndex, double totalPotential);
+/* setNodeWaterSinkSource    soilFluxes3D.h:51  soilFluxes3D.cpp:934-945 */
+sf3d_error_t sf3d_set_node_water_sink_source(uint32_t nodeIndex, double waterSinkSource);
+/* setNodePrescribedTotalPotential  soilFluxes3D.h:52  soilFluxes3D.cpp:913-927 */
+sf3d_error_t sf3d_set_node_prescribed_total_potential(uint32_t nodeIndex,
+                                                      double prescribedTotalPotential);
+
+/* ---- water getters --------------------------------------------------------------------- */
+
+/* getNodeWaterContent            soilFluxes3D.h:55  soilFluxes3D.cpp:951-961 */
+double sf3d_get_node_water_content(uint32_t nodeIndex);
+/* getNodeMaximumWaterContent     soilFluxes3D.h:56  soilFluxes3D.cpp:967-979 */
+double sf3d_get_node_maximum_water_content(uint32_t nodeIndex);
+/* getNodeMinimumWaterContent     soilFluxes3D.h:57  soilFluxes3D.cpp:986-998 */
+double sf3d_get_node_minimum_water_content(uint32_t nodeIndex);
+/* getNodeAvailableWaterContent   soilFluxes3D.h:58  soilFluxes3D.cpp:1005-1015 */
+double sf3d_get_node_available_water_content(uint32_t nodeIndex);
+/* getNodeWaterDeficit            soilFluxes3D.h:59  soilFluxes3D.cpp:1022-1034 */
+double sf3d_get_node_water_deficit(uint32_t nodeIndex, double fieldCapacity);
+/* getNodeDegreeOfSaturation      soilFluxes3D.h:60  soilFluxes3D.cpp:1041-1056 */
+double sf3d_get_node_degree_of_saturation(uint32_t nodeIndex);
+/* getNodeWaterConductivity       soilFluxes3D.h:61  soilFluxes3D.cpp:1062-1071 */
+double sf3d_get_node_water_conductivity(uint32_t nodeIndex);
+/* getNodeMatricPotential         soilFluxes3D.h:62  soilFluxes3D.cpp:1077-1086 */
+double sf3d_get_node_matric_potential(uint32_t nodeIndex);
+/* getNodeTotalPotential          soilFluxes3D.h:63  soilFluxes3D.cpp:1092-1101 */
+double sf3d_get_node_total_potential(uint32_t nodeIndex);
+/* getNodePond                    soilFluxes3D.h:64  soilFluxes3D.cpp:1107-1119 */
+double sf3d_get_node_pond(uint32_t nodeIndex);
+/* getNodeMaxWaterFlow            soilFluxes3D.h:65  soilFluxes3D.cpp:1126-1156 */
+double sf3d_get_node_max_water_flow(uint32_t nodeIndex, sf3d_link_t linkDirection);
+/* getNodeSumLateralWaterFlow     soilFluxes3D.h:66  soilFluxes3D.cpp:1162-1176 */
+double sf3d_get_node_sum_lateral_water_flow(uint32_t nodeIndex);
+/* getNodeSumLateralWaterFlowIn   soilFluxes3D.h:67  soilFluxes3D.cpp:1182-1196 */
+double sf3d_get_node_sum_lateral_water_flow_in(uint32_t nodeIndex);
+/* getNodeSumLateralWaterFlowOut  soilFluxes3D.h:68  soilFluxes3D.cpp:1202-1216 */
+double sf3d_get_node_sum_lateral_water_flow_out(uint32_t nodeIndex);
+/* getNodeBoundaryWaterFlow       soilFluxes3D.h:69  soilFluxes3D.cpp:1222-1234 */
+double sf3d_get_node_boundary_water_flow(uint32_t nodeIndex);
+/* getTotalBoundaryWaterFlow      soilFluxes3D.h:70  soilFluxes3D.cpp:1240-1250 */
+double sf3d_get_total_boundary_water_flow(sf3d_boundary_t boundaryType);
+/* getTotalWaterContent           soilFluxes3D.h:71  soilFluxes3D.cpp:1256-1259 */
+double sf3d_get_total_water_content(void);
+/* getWaterStorage                soilFluxes3D.h:72  soilFluxes3D.cpp:1265-1268 */
+double sf3d_get_water_storage(void);
+/* getWaterMBR                    soilFluxes3D.h:73  soilFluxes3D.cpp:1274-1277 */
+double sf3d_get_water_mbr(void);
+
+/* ---- heat setters (state is stored; heat transport itself is SURVEY.md 8f-2, "next") -- */
+
+/* setNodeHeatSinkSource             soilFluxes3D.h:76  soilFluxes3D.cpp:1283-1294 */
+sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t nodeIndex, double heatSinkSource);
+/* setNodeTemperature                soilFluxes3D.h:77  soilFluxes3D.cpp:1300-1312 */
+sf3d_error_t sf3d_set_node_temperature(uint32_t nodeIndex, double temperature);
+/* setNodeBoundaryFixedTemperature   soilFluxes3D.h:78  soilFluxes3D.cpp:1318-1336 */
+sf3d_error_t sf3d_set_node_boundary_fixed_temperature(uint32_t nodeIndex,
+                                                      double fixedTemperature, double depth);
+/* setNodeBoundaryHeightWind         soilFluxes3D.h:79  soilFluxes3D.cpp:1342-1356 */
+sf3d_error_t sf3d_set_node_boundary_height_wind(uint32_t nodeIndex, double heightWind);
+/* setNodeBoundaryHeightTemperature  soilFluxes3D.h:80  soilFluxes3D.cpp:1362-1376 */
+sf3d_error_t sf3d_set_node_boundary_height_temperature(uint32_t nodeIndex, double heightTemperature);
+/* setNodeBoundaryNetIrradiance      soilFluxes3D.h:81  soilFluxes3D.cpp:1382-1396 */
+sf3d_error_t sf3d_set_node_boundary_net_irradiance(uint32_t nodeIndex, double netIrradiance);
+/* setNodeBoundaryTemperature        soilFluxes3D.h:82  soilFluxes3D.cpp:1402-1416 */
+sf3d_error_t sf3d_set_node_boundary_temperature(uint32_t nodeIndex, double temperature);
+/* setNodeBoundaryRelativeHumidity   soilFluxes3D.h:83  soilFluxes3D.cpp:1422-1436 */
+sf3d_error_t sf3d_set_node_boundary_relative_humidity(uint32_t nodeIndex, double relativeHumidity);
+/* setNodeBoundaryRoughness          soilFluxes3D.h:84  soilFluxes3D.cpp:1442-1459 */
+sf3d_error_t sf3d_set_node_boundary_roughness(uint32_t nodeIndex, double roughness);
+/* setNodeBoundaryWindSpeed          soilFluxes3D.h:85  soilFluxes3D.cpp:1465-1482 */
+sf3d_error_t sf3d_set_node_boundary_wind_speed(uint32_t nodeIndex, double windSpeed);
+
+/* ---- heat getters ------------------------------------------------------------------------ */
+
+/* getNodeTemperature                soilFluxes3D.h:88  soilFluxes3D.cpp:1488-1500 */
+double sf3d_get_node_temperature(uint32_t nodeIndex);
+/* getNodeHeatConductivity           soilFluxes3D.h:89  soilFluxes3D.cpp:1506-1519 */
+double sf3d_get_node_heat_conductivity(uint32_t nodeIndex);
+/* getNodeVapor                      soilFluxes3D.h:90  soilFluxes3D.cpp:1525-1540 */
+double sf3d_get_node_vapor(uint32_t nodeIndex);
+/* getNodeHeatStorage                soilFluxes3D.h:91  soilFluxes3D.cpp:1547-1570 */
+double sf3d_get_node_heat_storage(uint32_t nodeIndex, double h);
+/* getNodeHeatMaxFlux                soilFluxes3D.h:92  soilFluxes3D.cpp:1578-1611 */
+double sf3d_get_node_heat_max_flux(uint32_t nodeIndex, sf3d_link_t linkDirection, sf3d_flux_t fluxType);
+/* getNodeBoundaryAdvectiveFlux      soilFluxes3D.h:93  soilFluxes3D.cpp:1617-1632 */
+double sf3d_get_node_boundary_advective_flux(uint32_t nodeIndex);
+/* getNodeBoundaryLatentFlux         soilFluxes3D.h:94  soilFluxes3D.cpp:1638-1653 */
+double sf3d_get_node_boundary_latent_flux(uint32_t nodeIndex);
+/* getNodeBoundaryRadiativeFlux      soilFluxes3D.h:95  soilFluxes3D.cpp:1659-1674 */
+double sf3d_get_node_boundary_radiative_flux(uint32_t nodeIndex);
+/* getNodeBoundarySensibleFlux       soilFluxes3D.h:96  soilFluxes3D.cpp:1680-1695 */
+double sf3d_get_node_boundary_sensible_flux(uint32_t nodeIndex);
+/* getNodeBoundaryAerodynamicConductance  soilFluxes3D.h:97  soilFluxes3D.cpp:1701-1716 */
+double sf3d_get_node_boundary_aerodynamic_conductance(uint32_t nodeIndex);
+/* getNodeBoundarySoilConductance    soilFluxes3D.h:98  soilFluxes3D.cpp:1722-1737 */
+double sf3d_get_node_boundary_soil_conductance(uint32_t nodeIndex);
+/* getHeatMBR                        soilFluxes3D.h:99  soilFluxes3D.cpp:1743-1746 */
+double sf3d_get_heat_mbr(void);
+/* getHeatMBE                        soilFluxes3D.h:100 soilFluxes3D.cpp:1750-1753 */
+double sf3d_get_heat_mbe(void);
+
+/* ---- computation --------------------------------------------------------------------------- */
+
+/* computePeriod   soilFluxes3D.h:103  soilFluxes3D.cpp:1760-1777 */
+void sf3d_compute_period(double timePeriod);
+/* computeStep     soilFluxes3D.h:104  soilFluxes3D.cpp:1785-1821  -> accepted dt [s] */
+double sf3d_compute_step(double maxTimeStep);
+
+/* ==================================================================================== */
+/* Extensions (not in the reference API).  None of them changes what the 70 calls above  */
+/* compute; they remove per-node call overhead and expose the counters  */
+/* the algorithmic-bytes model needs.                                      */
+/* ==================================================================================== */
+
+/* "hip" | "oracle" | "reference" */
+const char* sf3d_backend_name(void);
+
+/* Bulk forms: element k applies the scalar call above to node first+k (same validation, the
+ * first non-OK code is returned and processing stops there).  NULL optional arrays mean the
+ * scalar default. */
+sf3d_error_t sf3d_set_nodes(uint32_t first, uint32_t count, const double* x, const double* y,
+                            const double* z, const double* volume_or_area,
+                            const uint8_t* isSurface, const uint8_t* boundaryType,
+                            const double* slope, const double* boundaryArea);
+/* count link records: (node[k], linked[k], direction[k], area[k]) applied in array order */
+sf3d_error_t sf3d_set_node_links(uint64_t count, const uint32_t* node, const uint32_t* linked,
+                                 const uint8_t* direction, const double* interfaceArea);
+sf3d_error_t sf3d_set_nodes_soil(uint32_t first, uint32_t count, const uint16_t* soilIndex,
+                                 const uint16_t* horizonIndex);
+sf3d_error_t sf3d_set_nodes_surface(uint32_t first, uint32_t count, const uint16_t* surfaceIndex);
+sf3d_error_t sf3d_set_nodes_pond(uint32_t first, uint32_t count, const double* pond);
+sf3d_error_t sf3d_set_nodes_matric_potential(uint32_t first, uint32_t count, const double* psi);
+sf3d_error_t sf3d_set_nodes_total_potential(uint32_t first, uint32_t count, const double* H);
+sf3d_error_t sf3d_set_nodes_water_sink_source(uint32_t first, uint32_t count, const double* q);
+/* out[k] = getter(first+k) */
+sf3d_error_t sf3d_get_nodes_total_potential(uint32_t first, uint32_t count, double* out);
+sf3d_error_t sf3d_get_nodes_degree_of_saturation(uint32_t first, uint32_t count, double* out);
+sf3d_error_t sf3d_get_nodes_water_content(uint32_t first, uint32_t count, double* out);
+sf3d_error_t sf3d_get_nodes_water_conductivity(uint32_t first, uint32_t count, double* out);
+sf3d_error_t sf3d_get_nodes_boundary_water_flow(uint32_t first, uint32_t count, double* out);
+
+/* Work counters since sf3d_initialize (the same events SURVEY.md App. B instruments in
+ * cpusolver.cpp): out[0] attempts (waterMainLoop iterations), [1] accepted steps,
+ * [2] approximations, [3] Jacobi sweeps, [4] Courant rejections, [5] linear-solver failures,
+ * [6] restore-best calls, [7] reserved.  The "reference" backend cannot count (unmodified
+ * sources) and returns SF3D_MISSING_DATA_ERROR. */
+sf3d_error_t sf3d_get_counters(uint64_t out[8]);
+
+/* current adaptive time step deltaTcurr [s] (Solver::getTimeStep, solver.h:36) */
+double sf3d_get_time_step(void);
+/* Forget the adaptive time step so that the next sf3d_initialize starts from deltaTmax as a
+ * fresh process would (the reference keeps deltaTcurr across re-initialisations, SURVEY.md 8a
+ * quirk 4; benchmarks need a reproducible start).  "reference" backend: SF3D_MISSING_DATA_ERROR. */
+sf3d_error_t sf3d_reset_time_step(void);
+
+/* ---- device-side instrumentation (product backend only; others return MISSING_DATA) ------ */
+
+/* Select the HIP device for this process before sf3d_initialize (default: LOCAL_RANK or 0). */
+sf3d_error_t sf3d_set_device(int device);
+/* Block until all queued device work of the solver stream has finished. */
+sf3d_error_t sf3d_synchronize(void);
+/* Per-kernel HIP-event timing on the solver's own stream.  enable=1 starts recording an event
+ * pair around every launch of the kernels listed by sf3d_kernel_name(); enable=0 stops. */
+sf3d_error_t sf3d_kernel_timing(int enable);
+/* number of instrumented kernels; name of kernel k (NULL if out of range) */
+int          sf3d_kernel_count(void);
+const char*  sf3d_kernel_name(int k);
+/* launches, total milliseconds and nodes processed per launch of kernel k since timing was
+ * enabled (drains the event pool) */
+sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint64_t* nodes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF3D_H */
