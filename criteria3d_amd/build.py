@@ -1,0 +1,72 @@
+"""Build recipes: the HIP product library (gfx950), the C++ drop-in shim, and the test oracle.
+
+Everything is built IN-TREE so the shared objects travel with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "criteria3d_amd" / "csrc"
+INCLUDE = ROOT / "include"
+PRODUCT_LIB = CSRC / "libsf3d_hip.so"
+SHIM_LIB = ROOT / "shim" / "libsoilFluxes3D_mi355x.so"
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# -ffp-contract=off: products and sums must round separately, as in the reference's x86-64 -O2
+# build (no FMA contraction), so trajectories stay within the 1e-6 parity band.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def _run(cmd, **kw):
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if proc.returncode != 0:
+        raise RuntimeError(f"command failed ({proc.returncode}): {' '.join(map(str, cmd))}\n{proc.stdout}")
+    return proc.stdout
+
+
+def _stale(target: Path, sources) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(s).stat().st_mtime > t for s in sources)
+
+
+def build_product(force: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950: kernels + C ABI -> criteria3d_amd/csrc/libsf3d_hip.so"""
+    srcs = [CSRC / "sf3d_solver.hip", CSRC / "sf3d_api.cpp"]
+    deps = srcs + [CSRC / "sf3d_device.h", CSRC / "sf3d_model.h", INCLUDE / "sf3d.h"]
+    if force or _stale(PRODUCT_LIB, deps):
+        cmd = [HIPCC, *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-x", "hip", *map(str, srcs), "-o", str(PRODUCT_LIB)]
+        _run(cmd)
+    return PRODUCT_LIB
+
+
+def build_shim(force: bool = False) -> Path:
+    """The C++ drop-in: the reference's 70 soilFluxes3D::v2 symbols forwarding to the C ABI."""
+    src = ROOT / "shim" / "sf3d_cxx_shim.cpp"
+    if not src.exists():
+        return SHIM_LIB
+    deps = [src, ROOT / "shim" / "soilFluxes3D_api.h", INCLUDE / "sf3d.h"]
+    if force or _stale(SHIM_LIB, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{ROOT / 'shim'}", str(src),
+              "-o", str(SHIM_LIB), f"-L{CSRC}", "-lsf3d_hip", f"-Wl,-rpath,{CSRC}"])
+    return SHIM_LIB
+
+
+def build_oracle(with_reference: bool = True) -> None:
+    """Test infrastructure: the CPU restatement and (when /root/reference is present) oracle/_ref."""
+    _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
+    if with_reference:
+        _run(["make", "-C", str(ROOT / "oracle"), "ref"])
+
+
+def build_all(force: bool = False) -> None:
+    build_product(force)
+    build_shim(force)
+    build_oracle()

@@ -1,0 +1,553 @@
+/*
+ * sf3d_api.cpp - the C ABI of include/sf3d.h for the HIP product library (libsf3d_hip.so).
+ *
+ * Mirrors the reference's API layer (agrolib/soilFluxes3D/soilFluxes3D.cpp): same validation
+ * rules, return codes and sentinels, same call-order assumptions.  Setters write a host staging
+ * model and raise dirty flags (O(1), no device traffic); the time step itself runs on the GPU
+ * (sf3d_solver.hip).  There is NO CPU implementation of the time step in this library: without a
+ * HIP device computeStep fails loudly (message on stderr, NaN returned).
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+#include "sf3d_model.h"
+
+namespace {
+
+HostModel M;
+ParamsHost P;                                   /* persists across re-initialisation */
+std::vector<std::vector<uint16_t>> soil1D;      /* soil1DIndices, soilFluxes3D.cpp:39 */
+bool useLineal = false; int linealMethod = 0;
+struct Bal { double storage = 0, sinkSource = 0, MBE = 0, MBR = 0; };
+Bal curPeriod, wholePeriod;                     /* period balances live on the host (computePeriod) */
+double heatMBR = 0., heatMBE = 0.;
+uint64_t counterBase[8] = {0};
+
+DeviceSolver& dev() { return DeviceSolver::instance(); }
+
+double errValue(sf3d_error_t e)                  /* getDoubleErrorValue, types.h:42-64 */
+{
+    switch (e) {
+        case SF3D_OK: return 0;
+        case SF3D_INDEX_ERROR: return SF3D_VAL_INDEX_ERROR;
+        case SF3D_MEMORY_ERROR: return SF3D_VAL_MEMORY_ERROR;
+        case SF3D_TOPOGRAPHY_ERROR: return SF3D_VAL_TOPOGRAPHY_ERROR;
+        case SF3D_BOUNDARY_ERROR: return SF3D_VAL_BOUNDARY_ERROR;
+        case SF3D_MISSING_DATA_ERROR: return SF3D_VAL_MISSING_DATA_ERROR;
+        case SF3D_PARAMETER_ERROR: return SF3D_VAL_PARAMETER_ERROR;
+        default: return SF3D_VAL_INDEX_ERROR;
+    }
+}
+
+/* ---- host-side soil functions used by the state setters/getters only (soilPhysics.cpp) ---- */
+double seFromPsi(const SoilHost& s, double psi)                     /* :91-115 */
+{
+    switch (P.wrc) {
+        case SF3D_WRC_VAN_GENUCHTEN: return std::pow(1.0 + std::pow(s.alpha * psi, s.n), -s.m);
+        case SF3D_WRC_MODIFIED_VAN_GENUCHTEN:
+            if (psi <= s.he) return 1.0;
+            return std::pow(1.0 + std::pow(s.alpha * psi, s.n), -s.m) * (1.0 / s.Sc);
+        default: return SF3D_NODATA;
+    }
+}
+double nodeSe(uint32_t i)                                           /* :68-83 */
+{
+    if (M.H[i] >= M.z[i]) return 1.;
+    return seFromPsi(M.soils[M.cls[i]], std::fabs(M.H[i] - M.z[i]));
+}
+double mualemK(const SoilHost& s, double Se)                        /* :181-214 */
+{
+    if (Se >= 1.0) return s.Ksat;
+    const double invM = 1.0 / s.m;
+    double temp;
+    switch (P.wrc) {
+        case SF3D_WRC_VAN_GENUCHTEN: temp = 1.0 - std::pow(1.0 - std::pow(Se, invM), s.m); break;
+        case SF3D_WRC_MODIFIED_VAN_GENUCHTEN:
+            temp = (1.0 - std::pow(1.0 - std::pow(Se * s.Sc, invM), s.m)) / s.mualemDen; break;
+        default: return SF3D_NODATA;
+    }
+    return s.Ksat * std::pow(Se, s.L) * (temp * temp);
+}
+double thetaFromSe(const SoilHost& s, double Se) { return (Se * (s.thetaS - s.thetaR)) + s.thetaR; }   /* :38-42 */
+double nodeTheta(uint32_t i) { return M.surf[i] ? 1. : thetaFromSe(M.soils[M.cls[i]], M.Se[i]); }      /* :26-32 */
+double thetaFromSignedPsi(uint32_t i, double psi)                   /* :50-61 */
+{
+    if (M.surf[i]) return 1.;
+    const SoilHost& s = M.soils[M.cls[i]];
+    if (psi >= 0.) return s.thetaS;
+    return thetaFromSe(s, seFromPsi(s, std::fabs(psi)));
+}
+double seFromTheta(const SoilHost& s, double theta)                 /* :123-134 */
+{
+    if (theta >= s.thetaS) return 1.;
+    if (theta < s.thetaR) return 0.;
+    return (theta - s.thetaR) / (s.thetaS - s.thetaR);
+}
+double nodePsi(uint32_t i)                                          /* :140-158 */
+{
+    const SoilHost& s = M.soils[M.cls[i]];
+    double temp;
+    switch (P.wrc) {
+        case SF3D_WRC_VAN_GENUCHTEN: temp = std::pow(1. / M.Se[i], 1. / s.m) - 1.; break;
+        case SF3D_WRC_MODIFIED_VAN_GENUCHTEN: temp = std::pow(1. / (M.Se[i] * s.Sc), 1. / s.m) - 1; break;
+        default: return SF3D_NODATA;
+    }
+    return (1. / s.alpha) * std::pow(temp, 1. / s.n);
+}
+
+/* make the host copy of a field current before it is read or partially overwritten */
+bool needState()
+{
+    if (M.hostStaleState && dev().ready()) {
+        if (dev().fetch_state(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+        /* surface conventions of the setters (soilFluxes3D.cpp:819-820, 880-881) */
+        for (uint32_t i = 0; i < M.ns; ++i) { M.Se[i] = 1.; }
+    }
+    return true;
+}
+bool needFlows()
+{
+    if (M.hostStaleFlows && dev().ready())
+        if (dev().fetch_flows(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+    return true;
+}
+
+template <class T> void reset(std::vector<T>& v, size_t n) { v.assign(n, T()); }
+
+#define NEED_INIT_E   if (!M.initialized) return SF3D_MEMORY_ERROR
+#define NEED_NODE_E(i) if ((i) >= M.N) return SF3D_INDEX_ERROR
+#define NEED_INIT_D   if (!M.initialized) return errValue(SF3D_MEMORY_ERROR)
+#define NEED_NODE_D(i) if ((i) >= M.N) return errValue(SF3D_INDEX_ERROR)
+
+}  // namespace
+
+extern "C" {
+
+const char* sf3d_backend_name(void) { return "hip"; }
+
+sf3d_error_t sf3d_clean(void)                                       /* soilFluxes3D.cpp:218-304 */
+{
+    if (!M.initialized) return SF3D_OK;
+    dev().release();
+    M = HostModel();
+    return SF3D_OK;
+}
+
+sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h, int s, sf3d_heat_save_t)   /* :49-178 */
+{
+    sf3d_error_t c = sf3d_clean();
+    if (c != SF3D_OK) return c;
+    M.water = w != 0; M.heat = h != 0; M.solutes = s != 0;
+    M.N = n; M.ns = ns;
+    if (nLat > 8) return SF3D_PARAMETER_ERROR;
+    try {
+        reset(M.x, n); reset(M.y, n); reset(M.z, n); reset(M.size, n); reset(M.surf, n);
+        reset(M.hasClass, n); reset(M.cls, n); reset(M.btype, n); reset(M.bslope, n); reset(M.bsize, n);
+        reset(M.bflowRate, n); reset(M.bflowSum, n); reset(M.prescribed, n); reset(M.nLat, n);
+        for (int k = 0; k < SF3D_SLOTS; ++k) { reset(M.ltype[k], n); reset(M.lto[k], n); reset(M.larea[k], n); reset(M.lflowSum[k], n); }
+        reset(M.Se, n); reset(M.K, n); reset(M.H, n); reset(M.sink, n); reset(M.pond, n);
+        if (M.heat) { reset(M.temperature, n); reset(M.heatSink, n); }
+    } catch (const std::bad_alloc&) { return SF3D_MEMORY_ERROR; }
+    M.initialized = true;
+    if (P.dtCurr == SF3D_NODATA) P.dtCurr = P.dtMax;               /* CPUSolver::initialize, cpusolver.cpp:30-31 */
+    M.solverReady = true;
+    std::memset(counterBase, 0, sizeof(counterBase));
+    curPeriod = Bal(); wholePeriod = Bal();
+    return SF3D_OK;
+}
+
+sf3d_error_t sf3d_initialize_balance(void)                          /* soilFluxes3D.cpp:184-197, water.cpp:35-65 */
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    double wc = 0.;
+    sf3d_error_t e = dev().total_water_content(M, P, &wc);
+    if (e != SF3D_OK) { fprintf(stderr, "sf3d: initializeBalance: %s\n", dev().last_error()); return e; }
+    Ctrl& c = dev().ctrl();
+    wholePeriod.storage = curPeriod.storage = wc;
+    c.curStep.storage = c.prevStep.storage = wc;
+    c.curStep.sinkSource = c.prevStep.sinkSource = 0.; c.curPeriod.sinkSource = 0.;
+    curPeriod.sinkSource = wholePeriod.sinkSource = 0.;
+    c.curStep.MBR = 0.; wholePeriod.MBR = 0.; c.curStep.MBE = 0.; wholePeriod.MBE = 0.;
+    dev().push_ctrl();
+    needFlows();
+    for (int k = 0; k < SF3D_SLOTS; ++k) std::fill(M.lflowSum[k].begin(), M.lflowSum[k].end(), 0.);
+    std::fill(M.bflowSum.begin(), M.bflowSum.end(), 0.);
+    M.flowSumsDirty = true;
+    if (!M.heat) heatMBR = 1.;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_initialize_log(const char*, const char*) { return SF3D_OK; }   /* MCR logging is not built (parallel.pri:15-16) */
+sf3d_error_t sf3d_close_log(void) { return SF3D_OK; }
+sf3d_error_t sf3d_initialize_heat_flag(sf3d_heat_save_t, int, int) { return SF3D_OK; }
+
+uint32_t sf3d_set_threads_number(uint32_t n)                        /* soilFluxes3D.cpp:340-361: clamp and report; the GPU path has no host threads to set */
+{
+    uint32_t hw = std::thread::hardware_concurrency();
+    if (n < 1 || n > hw) n = hw;
+    if (M.solverReady) P.numThreads = n;
+    return n;
+}
+void sf3d_set_use_lineal(int v) { if (M.solverReady) useLineal = v != 0; }     /* the library's own Jacobi is always used */
+void sf3d_set_lineal_method(int v) { if (M.solverReady) linealMethod = v; }
+
+sf3d_error_t sf3d_set_soil_properties(uint16_t nrSoil, uint8_t nrHorizon, double alpha, double n, double m,
+                                      double he, double thetaR, double thetaS, double kSat, double L,
+                                      double om, double clay)       /* soilFluxes3D.cpp:395-449 */
+{
+    if (alpha <= 0 || n <= 1.0 || m <= 0.0 || m >= 1.0 || he < 0.0 || kSat <= 0.0 || thetaR < 0.0 ||
+        thetaR >= 1.0 || thetaS <= 0.0 || thetaS > 1.0 || thetaR > thetaS)
+        return SF3D_PARAMETER_ERROR;
+    for (const SoilHost& s : M.soils)
+        if (s.soilNumber == nrSoil && s.horizonNumber == nrHorizon) return SF3D_PARAMETER_ERROR;
+    if (M.soils.size() > std::numeric_limits<uint16_t>::max()) return SF3D_MEMORY_ERROR;
+    SoilHost s{nrSoil, nrHorizon, alpha, n, m, he, 0., thetaS, thetaR, kSat, L, om, clay, 0.};
+    s.Sc = std::pow(1. + std::pow(alpha * he, n), -m);
+    s.mualemDen = 1.0 - std::pow(1.0 - std::pow(s.Sc, 1.0 / m), m);
+    if (nrSoil >= soil1D.size()) soil1D.resize(nrSoil + 1);
+    if (nrHorizon >= soil1D[nrSoil].size()) soil1D[nrSoil].resize(nrHorizon + 1);
+    M.soils.push_back(s);
+    soil1D[nrSoil][nrHorizon] = (uint16_t)(M.soils.size() - 1);
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_surface_properties(uint16_t idx, double roughness)   /* soilFluxes3D.cpp:457-467 */
+{
+    if (roughness < 0) return SF3D_PARAMETER_ERROR;
+    if (idx >= M.roughness.size()) M.roughness.resize(idx + 1);
+    M.roughness[idx] = roughness;
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+
+sf3d_error_t sf3d_set_numerical_parameters(double minDt, double maxDt, uint16_t maxIter, uint16_t maxApprox,
+                                           uint8_t resExp, uint8_t mbrExp)   /* soilFluxes3D.cpp:474-520 */
+{
+    if (minDt < 0.01) minDt = 0.01;
+    if (minDt > 3600.) minDt = 3600.;
+    if (maxDt < 60) maxDt = 60;
+    if (maxDt > 3600.) maxDt = 3600.;
+    if (maxDt < minDt) maxDt = minDt;
+    if (maxIter < 20) maxIter = 20;
+    if (maxIter > 1000) maxIter = 1000;
+    if (maxApprox < 1) maxApprox = 1;
+    if (maxApprox > 50) maxApprox = 50;
+    if (resExp < 5) resExp = 5;
+    if (resExp > 12) resExp = 12;
+    if (mbrExp < 1) mbrExp = 1;
+    if (mbrExp > 9) mbrExp = 9;
+    if (!M.solverReady) return SF3D_MEMORY_ERROR;
+    P.MBRThreshold = std::pow(10.0, -mbrExp);
+    P.residualTolerance = std::pow(10.0, -resExp);
+    P.dtMin = minDt; P.dtMax = maxDt; P.maxApprox = maxApprox; P.maxIter = maxIter;
+    M.ctrlDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_hydraulic_properties(sf3d_wrc_t wrc, sf3d_mean_t mean, float ratio)   /* soilFluxes3D.cpp:531-548 */
+{
+    if ((ratio < 0.1) || (ratio > 100)) return SF3D_PARAMETER_ERROR;
+    if (!M.solverReady) return SF3D_MEMORY_ERROR;
+    P.wrc = wrc; P.meanType = mean; P.lvRatio = ratio;
+    M.ctrlDirty = true;
+    return SF3D_OK;
+}
+
+sf3d_error_t sf3d_set_culvert(uint32_t, double, double, double, double) { return SF3D_BOUNDARY_ERROR; }
+
+sf3d_error_t sf3d_set_node_boundary(uint32_t i, sf3d_boundary_t bt, double slope, double area)   /* soilFluxes3D.cpp:689-725 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);      /* the reference does not check; an out-of-range index there corrupts memory */
+    M.btype[i] = bt;
+    M.boundaryDirty = true;
+    if (bt == SF3D_BND_NONE) return SF3D_OK;
+    M.bslope[i] = slope; M.bsize[i] = area;
+    if (M.water) {
+        needFlows();
+        M.bflowRate[i] = 0.; M.bflowSum[i] = 0.; M.prescribed[i] = SF3D_NODATA;
+        M.flowSumsDirty = true;
+    }
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node(uint32_t i, double x, double y, double z, double v, int isSurf, sf3d_boundary_t bt,
+                           double slope, double barea)              /* soilFluxes3D.cpp:595-629 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    M.x[i] = x; M.y[i] = y; M.z[i] = z; M.size[i] = v;
+    M.surf[i] = isSurf != 0;
+    sf3d_set_node_boundary(i, bt, slope, barea);
+    if (M.water) { M.pond[i] = isSurf ? 0.0001f : SF3D_NODATA; M.sink[i] = 0.; M.pondDirty = M.sinkDirty = true; }
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_link(uint32_t i, uint32_t j, sf3d_link_t dir, double area)   /* soilFluxes3D.cpp:636-683 */
+{
+    NEED_INIT_E;
+    if (i >= M.N || j >= M.N) return SF3D_INDEX_ERROR;
+    int s;
+    switch (dir) {
+        case SF3D_LINK_UP: s = 0; break;
+        case SF3D_LINK_DOWN: s = 1; break;
+        case SF3D_LINK_LATERAL:
+            if (M.nLat[i] == 8) return SF3D_TOPOGRAPHY_ERROR;
+            s = 2 + M.nLat[i]; M.nLat[i]++;
+            break;
+        default: return SF3D_PARAMETER_ERROR;
+    }
+    M.ltype[s][i] = dir; M.lto[s][i] = j; M.larea[s][i] = area;
+    if (M.water) { if (M.hostStaleFlows) needFlows(); M.lflowSum[s][i] = 0.; M.flowSumsDirty = true; }
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_soil(uint32_t i, uint16_t soil, uint16_t horizon)   /* soilFluxes3D.cpp:734-750 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (M.surf[i]) return SF3D_INDEX_ERROR;
+    if (soil >= soil1D.size() || horizon >= soil1D[soil].size()) return SF3D_PARAMETER_ERROR;
+    M.cls[i] = soil1D[soil][horizon]; M.hasClass[i] = 1;
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_surface(uint32_t i, uint16_t surfaceIndex)   /* soilFluxes3D.cpp:758-775 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (surfaceIndex >= M.roughness.size()) return SF3D_PARAMETER_ERROR;
+    if (!M.surf[i]) return SF3D_INDEX_ERROR;
+    M.cls[i] = surfaceIndex; M.hasClass[i] = 1;
+    M.graphDirty = true;
+    return SF3D_OK;
+}
+
+sf3d_error_t sf3d_set_node_pond(uint32_t i, double pond)            /* soilFluxes3D.cpp:783-796 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (!M.surf[i]) return SF3D_INDEX_ERROR;
+    M.pond[i] = pond; M.pondDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_water_content(uint32_t i, double wc)     /* soilFluxes3D.cpp:803-835 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (wc < 0.) return SF3D_PARAMETER_ERROR;
+    if (!needState()) return SF3D_SOLVER_ERROR;
+    if (M.surf[i]) { M.H[i] = M.z[i] + wc; M.Se[i] = 1.; M.K[i] = 0.; }
+    else {
+        if (wc > 1.) return SF3D_PARAMETER_ERROR;
+        const SoilHost& s = M.soils[M.cls[i]];
+        M.Se[i] = seFromTheta(s, wc);
+        M.H[i] = M.z[i] - nodePsi(i);
+        M.K[i] = mualemK(s, M.Se[i]);
+    }
+    M.stateDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_degree_of_saturation(uint32_t i, double se)   /* soilFluxes3D.cpp:842-862 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (M.surf[i]) return SF3D_INDEX_ERROR;
+    if ((se < 0.) || (se > 1.)) return SF3D_PARAMETER_ERROR;
+    if (!needState()) return SF3D_SOLVER_ERROR;
+    M.Se[i] = se;
+    M.H[i] = M.z[i] - nodePsi(i);
+    M.K[i] = mualemK(M.soils[M.cls[i]], M.Se[i]);
+    M.stateDirty = true;
+    return SF3D_OK;
+}
+static sf3d_error_t setH(uint32_t i, double H)                      /* soilFluxes3D.cpp:877-883, 899-905 */
+{
+    if (!needState()) return SF3D_SOLVER_ERROR;
+    M.H[i] = H;
+    if (M.surf[i]) { M.Se[i] = 1.; M.K[i] = SF3D_NODATA; }
+    else { M.Se[i] = nodeSe(i); M.K[i] = mualemK(M.soils[M.cls[i]], M.Se[i]); }
+    M.stateDirty = true;
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_matric_potential(uint32_t i, double psi) { NEED_INIT_E; NEED_NODE_E(i); return setH(i, M.z[i] + psi); }
+sf3d_error_t sf3d_set_node_total_potential(uint32_t i, double H) { NEED_INIT_E; NEED_NODE_E(i); return setH(i, H); }
+sf3d_error_t sf3d_set_node_water_sink_source(uint32_t i, double q)  /* soilFluxes3D.cpp:934-945 */
+{ NEED_INIT_E; NEED_NODE_E(i); M.sink[i] = q; M.sinkDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_set_node_prescribed_total_potential(uint32_t i, double v)   /* soilFluxes3D.cpp:913-927 */
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    if (M.btype[i] != SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL) return SF3D_BOUNDARY_ERROR;
+    M.prescribed[i] = v; M.boundaryDirty = true;
+    return SF3D_OK;
+}
+
+/* ---- getters (soilFluxes3D.cpp:951-1277) ---- */
+double sf3d_get_node_water_content(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); needState(); return M.surf[i] ? (M.H[i] - M.z[i]) : nodeTheta(i); }
+double sf3d_get_node_maximum_water_content(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (M.surf[i]) return errValue(SF3D_INDEX_ERROR); return M.soils[M.cls[i]].thetaS; }
+double sf3d_get_node_minimum_water_content(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (M.surf[i]) return errValue(SF3D_INDEX_ERROR); return M.soils[M.cls[i]].thetaR; }
+double sf3d_get_node_available_water_content(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); needState(); return M.surf[i] ? (M.H[i] - M.z[i]) : std::max(0., nodeTheta(i) - thetaFromSignedPsi(i, -160)); }
+double sf3d_get_node_water_deficit(uint32_t i, double fc)
+{ NEED_INIT_D; NEED_NODE_D(i); if (M.surf[i]) return 0.; needState(); return thetaFromSignedPsi(i, -fc) - nodeTheta(i); }
+double sf3d_get_node_degree_of_saturation(uint32_t i)
+{
+    NEED_INIT_D; NEED_NODE_D(i); needState();
+    if (!M.surf[i]) return M.Se[i];
+    const double cur = M.H[i] - M.z[i], mx = 0.001;
+    return cur <= 0 ? 0 : (cur > mx ? 1. : cur / mx);
+}
+double sf3d_get_node_water_conductivity(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); needState(); return M.K[i]; }
+double sf3d_get_node_matric_potential(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); needState(); return M.H[i] - M.z[i]; }
+double sf3d_get_node_total_potential(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); needState(); return M.H[i]; }
+double sf3d_get_node_pond(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (!M.surf[i]) return errValue(SF3D_INDEX_ERROR); return M.pond[i]; }
+double sf3d_get_node_max_water_flow(uint32_t i, sf3d_link_t dir)
+{
+    NEED_INIT_D; NEED_NODE_D(i); needFlows();
+    double mx = 0.;
+    switch (dir) {
+        case SF3D_LINK_UP: return M.lflowSum[0][i];
+        case SF3D_LINK_DOWN: return M.lflowSum[1][i];
+        case SF3D_LINK_LATERAL:
+            for (int l = 0; l < M.nLat[i]; ++l) mx = std::max(mx, M.lflowSum[2 + l][i]);
+            return mx;
+        default: return errValue(SF3D_INDEX_ERROR);
+    }
+}
+double sf3d_get_node_sum_lateral_water_flow(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); needFlows(); double s = 0.; for (int l = 0; l < M.nLat[i]; ++l) s += M.lflowSum[2 + l][i]; return s; }
+double sf3d_get_node_sum_lateral_water_flow_in(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); needFlows(); double s = 0.; for (int l = 0; l < M.nLat[i]; ++l) if (M.lflowSum[2 + l][i] > 0) s += M.lflowSum[2 + l][i]; return s; }
+double sf3d_get_node_sum_lateral_water_flow_out(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); needFlows(); double s = 0.; for (int l = 0; l < M.nLat[i]; ++l) if (M.lflowSum[2 + l][i] < 0) s += M.lflowSum[2 + l][i]; return s; }
+double sf3d_get_node_boundary_water_flow(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (M.btype[i] == SF3D_BND_NONE) return errValue(SF3D_BOUNDARY_ERROR); needFlows(); return M.bflowSum[i]; }
+double sf3d_get_total_boundary_water_flow(sf3d_boundary_t bt)       /* soilFluxes3D.cpp:1240-1250, index order */
+{ needFlows(); double s = 0.0; for (uint32_t i = 0; i < M.N; ++i) if (M.btype[i] == bt) s += M.bflowSum[i]; return s; }
+double sf3d_get_total_water_content(void)                           /* soilFluxes3D.cpp:1256-1259 */
+{
+    if (!M.initialized) return -1;
+    double wc = 0.;
+    if (dev().total_water_content(M, P, &wc) != SF3D_OK) { fprintf(stderr, "sf3d: getTotalWaterContent: %s\n", dev().last_error()); return std::nan(""); }
+    return wc;
+}
+double sf3d_get_water_storage(void) { return dev().ctrl().curStep.storage; }
+double sf3d_get_water_mbr(void) { return wholePeriod.MBR; }
+
+/* ---- heat: state is staged when heat was requested; transport is not implemented (8f-2) ---- */
+#define HEAT_OFF_E if (!M.heat) return SF3D_MISSING_DATA_ERROR
+sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.heatSink[i] = v; return SF3D_OK; }
+sf3d_error_t sf3d_set_node_temperature(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.temperature[i] = v; return SF3D_OK; }
+#define HEAT_BND_SET(NAME) sf3d_error_t NAME(uint32_t i, double) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; \
+    if (M.btype[i] == SF3D_BND_NONE) return SF3D_BOUNDARY_ERROR; return SF3D_MISSING_DATA_ERROR; }
+HEAT_BND_SET(sf3d_set_node_boundary_height_wind) HEAT_BND_SET(sf3d_set_node_boundary_height_temperature)
+HEAT_BND_SET(sf3d_set_node_boundary_net_irradiance) HEAT_BND_SET(sf3d_set_node_boundary_temperature)
+HEAT_BND_SET(sf3d_set_node_boundary_relative_humidity) HEAT_BND_SET(sf3d_set_node_boundary_roughness)
+HEAT_BND_SET(sf3d_set_node_boundary_wind_speed)
+sf3d_error_t sf3d_set_node_boundary_fixed_temperature(uint32_t i, double, double) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; return SF3D_MISSING_DATA_ERROR; }
+double sf3d_get_node_temperature(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (!M.heat || M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); return M.temperature[i]; }
+#define HEAT_GET(NAME) double NAME(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
+HEAT_GET(sf3d_get_node_heat_conductivity) HEAT_GET(sf3d_get_node_vapor)
+HEAT_GET(sf3d_get_node_boundary_advective_flux) HEAT_GET(sf3d_get_node_boundary_latent_flux)
+HEAT_GET(sf3d_get_node_boundary_radiative_flux) HEAT_GET(sf3d_get_node_boundary_sensible_flux)
+HEAT_GET(sf3d_get_node_boundary_aerodynamic_conductance) HEAT_GET(sf3d_get_node_boundary_soil_conductance)
+double sf3d_get_node_heat_storage(uint32_t i, double) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
+double sf3d_get_node_heat_max_flux(uint32_t i, sf3d_link_t, sf3d_flux_t) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
+double sf3d_get_heat_mbr(void) { return heatMBR; }
+double sf3d_get_heat_mbe(void) { return heatMBE; }
+
+/* ---- computation ---- */
+double sf3d_compute_step(double maxDt)                               /* soilFluxes3D.cpp:1785-1821 */
+{
+    if (!M.water) return std::min(maxDt, P.dtMax);
+    if (!M.initialized || !M.solverReady) { fprintf(stderr, "sf3d: computeStep before initializeSF3D\n"); return std::nan(""); }
+    double dt = std::nan("");
+    sf3d_error_t e = dev().step(M, P, maxDt, &dt);
+    if (e != SF3D_OK && !(dt == dt)) {
+        fprintf(stderr, "sf3d: computeStep failed on the HIP device: %s\n", dev().last_error());
+        return std::nan("");
+    }
+    return dt;
+}
+void sf3d_compute_period(double period)                              /* soilFluxes3D.cpp:1760-1777, water.cpp:143-156 */
+{
+    if (!M.initialized) return;
+    if (dev().ready()) { dev().ctrl().curPeriod.sinkSource = 0.; dev().push_ctrl(); }
+    double t = 0.;
+    while (t < period) {
+        const double dt = sf3d_compute_step(period - t);
+        if (!(dt > 0.)) return;                                      /* device failure: do not spin */
+        t += dt;
+    }
+    if (M.water) {
+        const Ctrl& c = dev().ctrl();
+        curPeriod.sinkSource = c.curPeriod.sinkSource;
+        wholePeriod.sinkSource += curPeriod.sinkSource;
+        const double dSp = c.curStep.storage - curPeriod.storage;
+        const double dSh = c.curStep.storage - wholePeriod.storage;
+        curPeriod.MBE = dSp - curPeriod.sinkSource;
+        wholePeriod.MBE = dSh - wholePeriod.sinkSource;
+        const double ref = std::max(0.001, wholePeriod.sinkSource);
+        wholePeriod.MBR = wholePeriod.MBE / ref;
+        curPeriod.storage = c.curStep.storage;
+    }
+}
+
+/* ---- extensions ---- */
+sf3d_error_t sf3d_set_nodes(uint32_t first, uint32_t count, const double* x, const double* y, const double* z,
+                            const double* v, const uint8_t* surf, const uint8_t* bt, const double* sl, const double* ba)
+{
+    for (uint32_t k = 0; k < count; ++k) {
+        sf3d_error_t e = sf3d_set_node(first + k, x[k], y[k], z[k], v[k], surf[k], bt ? bt[k] : 0, sl ? sl[k] : 0., ba ? ba[k] : 0.);
+        if (e != SF3D_OK) return e;
+    }
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_set_node_links(uint64_t count, const uint32_t* node, const uint32_t* linked, const uint8_t* dir, const double* area)
+{
+    for (uint64_t k = 0; k < count; ++k) {
+        sf3d_error_t e = sf3d_set_node_link(node[k], linked[k], dir[k], area[k]);
+        if (e != SF3D_OK) return e;
+    }
+    return SF3D_OK;
+}
+#define BULK_SET(NAME, CALL, ...)                                                     \
+    sf3d_error_t NAME(uint32_t first, uint32_t count, __VA_ARGS__)                     \
+    { for (uint32_t k = 0; k < count; ++k) { sf3d_error_t e = CALL; if (e != SF3D_OK) return e; } return SF3D_OK; }
+BULK_SET(sf3d_set_nodes_soil, sf3d_set_node_soil(first + k, s[k], h ? h[k] : 0), const uint16_t* s, const uint16_t* h)
+BULK_SET(sf3d_set_nodes_surface, sf3d_set_node_surface(first + k, s[k]), const uint16_t* s)
+BULK_SET(sf3d_set_nodes_pond, sf3d_set_node_pond(first + k, v[k]), const double* v)
+BULK_SET(sf3d_set_nodes_matric_potential, sf3d_set_node_matric_potential(first + k, v[k]), const double* v)
+BULK_SET(sf3d_set_nodes_total_potential, sf3d_set_node_total_potential(first + k, v[k]), const double* v)
+BULK_SET(sf3d_set_nodes_water_sink_source, sf3d_set_node_water_sink_source(first + k, v[k]), const double* v)
+#define BULK_GET(NAME, CALL)                                                          \
+    sf3d_error_t NAME(uint32_t first, uint32_t count, double* out)                     \
+    { for (uint32_t k = 0; k < count; ++k) out[k] = CALL(first + k); return SF3D_OK; }
+BULK_GET(sf3d_get_nodes_total_potential, sf3d_get_node_total_potential)
+BULK_GET(sf3d_get_nodes_degree_of_saturation, sf3d_get_node_degree_of_saturation)
+BULK_GET(sf3d_get_nodes_water_content, sf3d_get_node_water_content)
+BULK_GET(sf3d_get_nodes_water_conductivity, sf3d_get_node_water_conductivity)
+BULK_GET(sf3d_get_nodes_boundary_water_flow, sf3d_get_node_boundary_water_flow)
+
+sf3d_error_t sf3d_get_counters(uint64_t out[8])
+{
+    const Ctrl& c = dev().ctrl();
+    for (int k = 0; k < 8; ++k) out[k] = dev().ready() ? c.counters[k] : 0;
+    out[7] = 0;
+    return SF3D_OK;
+}
+double sf3d_get_time_step(void) { return P.dtCurr; }
+sf3d_error_t sf3d_reset_time_step(void) { P.dtCurr = SF3D_NODATA; M.ctrlDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_set_device(int d)
+{
+    sf3d_error_t e = dev().set_device(d);
+    if (e != SF3D_OK) fprintf(stderr, "sf3d: set_device: %s\n", dev().last_error());
+    return e;
+}
+sf3d_error_t sf3d_synchronize(void) { return dev().synchronize(); }
+sf3d_error_t sf3d_kernel_timing(int enable) { return dev().timing(enable != 0); }
+int sf3d_kernel_count(void) { return KID_COUNT; }
+const char* sf3d_kernel_name(int k) { return DeviceSolver::kernel_name(k); }
+sf3d_error_t sf3d_kernel_stats(int k, uint64_t* n, double* ms, uint64_t* nodes) { return dev().stats(k, n, ms, nodes); }
+
+} /* extern "C" */

@@ -1,0 +1,97 @@
+/*
+ * sf3d_device.h - structures shared by the host model (sf3d_api.cpp) and the HIP solver
+ * (sf3d_solver.hip) of the MI355X-native soilFluxes3D library.
+ *
+ * Data layout in HBM (all fp64 unless noted, node arrays in caller order: layer-major,
+ * surface nodes first - the ordering the reference relies on):
+ *   static graph   lto[10][N] u32, lkind[10][N] u8, larea[10][N], ldist[10][N]  (slot-major:
+ *                  slot 0 Up, 1 Down, 2..9 laterals; consecutive threads read consecutive
+ *                  nodes of one slot => coalesced), z, size, pond, cls u16, btype u8,
+ *                  bslope, bsize, prescribed
+ *   soil classes   SoilDev[] (gathered by cls, L2/scalar-cache resident)
+ *   state          X[4][N]: pool of head buffers; H, Hold and Hbest are INDICES into the
+ *                  pool kept in Ctrl (no copies on step begin / reject / keep-best / restore)
+ *                  Se, K, C, flow, sink, bflowRate, bflowSum, lflowSum[10][N]
+ *   linear system  A[10][N] row-normalised off-diagonals (static ELL, zeros kept), b
+ *   control block  Ctrl: solver parameters, adaptive dt, stage of the step state machine,
+ *                  balances, counters - decisions are taken on the device by 1-block kernels
+ */
+#ifndef SF3D_DEVICE_H
+#define SF3D_DEVICE_H
+
+#include <stdint.h>
+
+#define SF3D_SLOTS 10
+#define SF3D_POOL 4
+#define SF3D_BLOCK 256
+
+/* link kinds (derived once per graph change from the two end nodes, water.cpp:308-324) */
+enum : uint8_t { LK_NONE = 0, LK_SOIL_VERT = 1, LK_SOIL_LAT = 2, LK_RUNOFF = 3, LK_INFILTRATION = 4 };
+
+/* stages of the device-resident step state machine (cpusolver.cpp:143-190, 392-468) */
+enum : uint32_t {
+    ST_IDLE = 0,        /* between computeStep calls                                         */
+    ST_ATTEMPT = 1,     /* begin an attempt: dt = min(dtCurr, max), Hold = H                 */
+    ST_APPROX = 2,      /* properties + boundary + assembly of approximation `approx`        */
+    ST_SWEEP = 3,       /* Jacobi sweeps running                                             */
+    ST_POST = 4,        /* H = x, Se, balance sums                                           */
+    ST_RESTORE = 5,     /* restoreBestStep: H = Hbest, Se, K, boundary, balance              */
+    ST_ACCEPT = 6,      /* acceptStep: flow sums                                             */
+    ST_DONE = 7,        /* step accepted                                                     */
+    ST_FAIL = 8         /* stepNan                                                           */
+};
+
+struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
+    double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
+};
+
+struct BalanceDev { double storage, sinkSource, MBE, MBR; };
+
+struct Ctrl {
+    /* ---- parameters (SolverParameters, types.h:291-315) ---- */
+    double MBRThreshold, residualTolerance, dtMin, dtMax, lvRatio, courantThreshold, instabilityFactor;
+    uint32_t maxApprox, maxIter;
+    uint32_t wrc, meanType;
+    /* ---- adaptive state ---- */
+    double dtCurr;          /* deltaTcurr                                  */
+    double dt;              /* dt of the running attempt                   */
+    double maxTimeStep;     /* argument of computeStep                     */
+    double courant;         /* nodeGrid.CourantWater                       */
+    double bestMBR;         /* _bestMBRerror                               */
+    double bestNorm;        /* bestErrorNorm of solveLinearSystem          */
+    double lastNorm;
+    uint32_t stage, approx, iter, iterBudget;
+    int32_t cur, hold, best; /* indices into the X pool; best = -1 when none */
+    uint32_t linearValid;
+    /* ---- balances (balanceData_t x4, soilFluxes3D.cpp:37) ---- */
+    BalanceDev curStep, prevStep, curPeriod, wholePeriod;
+    /* ---- query results (getTotalWaterContent etc.) ---- */
+    double query[2];
+    /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
+    uint64_t counters[8];
+};
+
+struct DevView {
+    uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
+    const double *z, *size, *pond, *sink;
+    const uint16_t* cls;
+    const uint8_t* btype;
+    const double *bslope, *bsize, *prescribed;
+    const uint32_t* lto;                /* [10][N] */
+    const uint8_t* lkind;               /* [10][N] */
+    const double *larea, *ldist;        /* [10][N] */
+    double* lflowSum;                   /* [10][N] */
+    double* A;                          /* [10][N] */
+    double *b, *C;
+    double* X[SF3D_POOL];
+    double *Se, *K, *flow, *bflowRate, *bflowSum;
+    double *part0, *part1;              /* per-block partials [nb] */
+    const SoilDev* soils;
+    const double* roughness;
+    Ctrl* ctrl;
+};
+
+/* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */
+enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_COUNT };
+
+#endif

@@ -1,0 +1,96 @@
+/*
+ * sf3d_model.h - host-side staging model of the MI355X soilFluxes3D library and the interface
+ * of the device solver.  Setters of the C ABI only touch this staging copy (O(1) host work per
+ * call, SURVEY.md 7 "chatty API"); the device is brought up to date lazily at the next
+ * computeStep / initializeBalance, and getters pull a field back only when the device holds a
+ * newer version of it.
+ */
+#ifndef SF3D_MODEL_H
+#define SF3D_MODEL_H
+
+#include <cstdint>
+#include <vector>
+
+#include "sf3d.h"
+#include "sf3d_device.h"
+
+struct SoilHost {                      /* soilData_t, types.h:104-121 */
+    uint16_t soilNumber; uint8_t horizonNumber;
+    double alpha, n, m, he, Sc, thetaS, thetaR, Ksat, L, organicMatter, clay;
+    double mualemDen;                  /* 1 - (1 - Sc^(1/m))^m, soilPhysics.cpp:201-204 */
+};
+
+struct ParamsHost {                    /* SolverParameters, types.h:291-315 (persist across re-init) */
+    double MBRThreshold = 1e-3, residualTolerance = 1e-10;
+    double dtMin = 1, dtMax = 600, dtCurr = SF3D_NODATA;
+    uint16_t maxApprox = 10, maxIter = 200;
+    uint8_t wrc = SF3D_WRC_MODIFIED_VAN_GENUCHTEN, meanType = SF3D_MEAN_LOGARITHMIC;
+    double lvRatio = 4., courantThreshold = 0.5, instabilityFactor = 10.;
+    uint32_t numThreads = 1;
+};
+
+struct HostModel {
+    bool initialized = false, solverReady = false;
+    bool water = true, heat = false, solutes = false;
+    uint32_t N = 0, ns = 0;
+    std::vector<double> x, y, z, size;
+    std::vector<uint8_t> surf, hasClass;
+    std::vector<uint16_t> cls;
+    std::vector<uint8_t> btype;
+    std::vector<double> bslope, bsize, bflowRate, bflowSum, prescribed;
+    std::vector<uint8_t> nLat;
+    std::vector<uint8_t> ltype[SF3D_SLOTS];
+    std::vector<uint32_t> lto[SF3D_SLOTS];
+    std::vector<double> larea[SF3D_SLOTS], lflowSum[SF3D_SLOTS];
+    std::vector<double> Se, K, H, sink, pond;
+    std::vector<SoilHost> soils;
+    std::vector<double> roughness;
+    /* heat state is staged only (transport: SURVEY.md 8f-2) */
+    std::vector<double> temperature, heatSink;
+
+    /* what the device lacks */
+    bool graphDirty = true;      /* topology / classes / boundary geometry: rebuild + full upload */
+    bool stateDirty = true;      /* H (and Se, K) set through the API                             */
+    bool sinkDirty = true, pondDirty = true, boundaryDirty = true, flowSumsDirty = true;
+    bool ctrlDirty = true;       /* parameters or balances edited on the host                     */
+    /* what the host lacks (device is newer) */
+    bool hostStaleState = false; /* H, Se, K                                                      */
+    bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */
+};
+
+/* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR
+ * and leave a message retrievable with last_error(). */
+class DeviceSolver {
+public:
+    static DeviceSolver& instance();
+    sf3d_error_t set_device(int dev);
+    /* bring the device up to date with every dirty part of `m` (allocates on first use) */
+    sf3d_error_t sync_to_device(HostModel& m, const ParamsHost& p);
+    /* one computeStep: returns the accepted dt through *dt and refreshes the Ctrl mirror */
+    sf3d_error_t step(HostModel& m, ParamsHost& p, double maxTimeStep, double* dt);
+    /* storage = sum(theta * size) over the device state (water.cpp:71-90) */
+    sf3d_error_t total_water_content(HostModel& m, const ParamsHost& p, double* out);
+    sf3d_error_t fetch_state(HostModel& m);      /* H, Se, K   -> host */
+    sf3d_error_t fetch_flows(HostModel& m);      /* flow sums  -> host */
+    sf3d_error_t release();
+    sf3d_error_t synchronize();
+    Ctrl& ctrl() { return mirror_; }
+    void push_ctrl() { ctrlEdited_ = true; }
+    bool ready() const { return built_; }
+    const char* last_error() const { return err_; }
+    /* instrumentation */
+    sf3d_error_t timing(bool enable);
+    sf3d_error_t stats(int kid, uint64_t* launches, double* ms, uint64_t* nodes);
+    static const char* kernel_name(int kid);
+
+private:
+    DeviceSolver() = default;
+    struct Impl;
+    Impl* impl_ = nullptr;
+    Ctrl mirror_{};
+    bool built_ = false, ctrlEdited_ = false;
+    char err_[256] = {0};
+    friend struct Impl;
+};
+
+#endif

@@ -1,0 +1,1012 @@
+/*
+ * sf3d_solver.hip - HIP/CDNA4 (gfx950) kernels and device-resident step control of the
+ * MI355X-native soilFluxes3D water time step.
+ *
+ * What it computes is the reference's CPU/OpenMP path (cpusolver.cpp:143-190 waterMainLoop,
+ * :392-468 waterApproximationLoop, :672-703 solveLinearSystem; water.cpp; soilPhysics.cpp);
+ * how it computes it is designed for the MI355X:
+ *   - one thread per node over slot-major (coalesced) graph arrays, fp64 throughout, no MFMA
+ *     (11-point unstructured stencil); -ffp-contract=off so products and sums round as in the
+ *     reference's x86-64 -O2 build;
+ *   - properties + boundary fused in one kernel, assembly + diagonal + row normalisation +
+ *     Courant maximum fused in one kernel, Jacobi sweep + surface clamp + norm fused in one
+ *     kernel, post-solve Se + both mass-balance sums fused in one kernel;
+ *   - H / Hold / Hbest are indices into a pool of four head buffers: step begin, rejection,
+ *     keep-best and restore-best are index flips, not N-element copies;
+ *   - every accept / halve / Courant / convergence decision is taken ON THE DEVICE by a
+ *     one-block kernel that reduces the per-block partials in a fixed order (deterministic,
+ *     wave64 shuffles + LDS) and advances a stage machine in the control block; every compute
+ *     kernel is guarded by that stage, so the host can queue a whole approximation (with a
+ *     speculative batch of sweeps) without reading anything back, and polls the control block
+ *     once per approximation instead of once per kernel.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "sf3d_model.h"
+
+#define NODATA_D (-9999.0)
+
+/* ======================================================================================= */
+/* device helpers                                                                           */
+/* ======================================================================================= */
+
+/* std::max / std::min semantics (NaN handling included) */
+__device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
+
+__device__ __forceinline__ int free_buffer(const Ctrl* c)
+{
+    for (int b = 0; b < SF3D_POOL; ++b)
+        if (b != c->cur && b != c->hold && b != c->best) return b;
+    return 0;   /* unreachable: at most three of four buffers are in use */
+}
+
+/* fixed-shape block reductions (256 threads = 4 waves of 64) */
+__device__ __forceinline__ double block_sum(double v)
+{
+    __shared__ double sm[SF3D_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__device__ __forceinline__ double block_max(double v)
+{
+    __shared__ double sm[SF3D_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) v = dmax(v, __shfl_down(v, off, 64));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return dmax(dmax(sm[0], sm[1]), dmax(sm[2], sm[3]));
+}
+/* one block reduces nb partials in a fixed order */
+__device__ __forceinline__ double reduce_partials_sum(const double* p, uint32_t nb)
+{
+    double s = 0.;
+    for (uint32_t k = threadIdx.x; k < nb; k += SF3D_BLOCK) s += p[k];
+    return block_sum(s);
+}
+__device__ __forceinline__ double reduce_partials_max(const double* p, uint32_t nb)
+{
+    double s = 0.;
+    for (uint32_t k = threadIdx.x; k < nb; k += SF3D_BLOCK) s = dmax(s, p[k]);
+    return block_max(s);
+}
+
+/* ---- Math::computeMean (otherFunctions.cpp:7-36) ---- */
+__device__ __forceinline__ double mean_of(double v1, double v2, uint32_t type)
+{
+    if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
+    if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
+    return (v1 == v2) ? v1 : (v1 - v2) / log(v1 / v2);
+}
+
+/* ---- Soil:: (soilPhysics.cpp) ---- */
+__device__ __forceinline__ double se_from_psi(const SoilDev& s, double psi, uint32_t wrc)   /* :91-115 */
+{
+    if (wrc == SF3D_WRC_VAN_GENUCHTEN) return pow(1.0 + pow(s.alpha * psi, s.n), -s.m);
+    if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) {
+        if (psi <= s.he) return 1.0;
+        return pow(1.0 + pow(s.alpha * psi, s.n), -s.m) * s.invSc;
+    }
+    return NODATA_D;
+}
+__device__ __forceinline__ double node_se(const SoilDev& s, double H, double z, uint32_t wrc)  /* :68-83 */
+{
+    if (H >= z) return 1.;
+    return se_from_psi(s, fabs(H - z), wrc);
+}
+__device__ __forceinline__ double mualem_k(const SoilDev& s, double Se, uint32_t wrc)          /* :181-214 */
+{
+    if (Se >= 1.0) return s.Ksat;
+    double temp;
+    if (wrc == SF3D_WRC_VAN_GENUCHTEN) {
+        const double sePow = pow(Se, s.invM);
+        temp = 1.0 - pow(1.0 - sePow, s.m);
+    } else if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) {
+        const double seScPow = pow(Se * s.Sc, s.invM);
+        const double tNum = 1.0 - pow(1.0 - seScPow, s.m);
+        temp = tNum / s.mualemDen;
+    } else return NODATA_D;
+    return s.Ksat * pow(Se, s.L) * (temp * temp);
+}
+__device__ __forceinline__ double dtheta_dh(const SoilDev& s, double H, double Ho, double z, uint32_t wrc)   /* :224-279 */
+{
+    const double psiCurr = fabs(dmin(0.0, H - z));
+    const double psiPrev = fabs(dmin(0.0, Ho - z));
+    if (wrc == SF3D_WRC_VAN_GENUCHTEN) { if (psiCurr == 0.0 && psiPrev == 0.0) return 0.0; }
+    else if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) { if (psiCurr <= s.he && psiPrev <= s.he) return 0.0; }
+    double dSe;
+    if (fabs(psiCurr - psiPrev) < 1e-12) {
+        const double xx = s.alpha * psiCurr;
+        const double onePlus = 1. + pow(xx, s.n);
+        const double t1 = pow(onePlus, -(s.m + 1.));
+        const double t2 = pow(xx, s.n - 1.);
+        dSe = s.alpha * s.n * s.m * t1 * t2;
+        if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) dSe *= s.invSc;
+    } else {
+        const double a = se_from_psi(s, psiCurr, wrc), c = se_from_psi(s, psiPrev, wrc);
+        dSe = fabs((a - c) / (H - Ho));
+    }
+    return dSe * (s.thetaS - s.thetaR);
+}
+
+/* ---- waterFlow = sink (+ evaporation clamp) + boundary flow (water.cpp:632-807) ---- */
+__device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c, uint32_t i, double H, double Ho,
+                                                double z, double K)
+{
+    const double dt = c->dt;
+    double flow = v.sink[i];
+    if (i < v.ns && flow < 0) {                                       /* :646-652 */
+        const double avgH = 0.5 * (H + Ho);
+        const double hs = dmax(0., avgH - z);
+        const double maxFlux = -hs * v.size[i] / dt;
+        flow = dmax(flow, maxFlux);
+    }
+    const uint8_t bt = v.btype[i];
+    if (bt != SF3D_BND_NONE) {
+        double rate = 0.;
+        switch (bt) {
+            case SF3D_BND_RUNOFF: {                                   /* :661-678 */
+                const double avgH = 0.5 * (H + Ho);
+                const double hs = dmax(0., avgH - (z + v.pond[i]));
+                if (hs < 0.001) break;
+                const double maxFlow = (hs * v.size[i]) / dt;
+                const double vel = pow(hs, 2. / 3.) * sqrt(v.bslope[i]) / v.roughness[v.cls[i]];
+                const double val = hs * vel * v.bsize[i];
+                rate = -dmin(val, maxFlow);
+                break; }
+            case SF3D_BND_FREE_DRAINAGE:                              /* :680-684, Up-link area */
+                rate = -K * v.larea[i];
+                break;
+            case SF3D_BND_FREE_LATERAL_DRAINAGE:                      /* :686-690 */
+                rate = -K * v.bsize[i] * v.bslope[i] * c->lvRatio;
+                break;
+            case SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL: {               /* :692-706 */
+                const SoilDev s = v.soils[v.cls[i]];
+                const double L = 1.;
+                const double bz = z - L;
+                const double pH = v.prescribed[i];
+                const double bpsi = pH - bz;
+                const double bK = (bpsi >= 0) ? s.Ksat : mualem_k(s, se_from_psi(s, fabs(bpsi), c->wrc), c->wrc);
+                const double mk = mean_of(bK, K, c->meanType);
+                rate = mk * v.bsize[i] * ((pH - H) / L);
+                break; }
+            default: rate = 0.; break;                                /* Urban/Road/Culvert/HeatSurface w/o heat */
+        }
+        if (fabs(rate) < DBL_EPSILON) rate = 0.;                      /* :802-805 */
+        else flow += rate;
+        v.bflowRate[i] = rate;
+    }
+    v.flow[i] = flow;
+}
+
+/* ======================================================================================= */
+/* control kernels (one thread / one block)                                                 */
+/* ======================================================================================= */
+
+__global__ void k_step_begin(Ctrl* c, double maxTimeStep)
+{
+    c->maxTimeStep = maxTimeStep;
+    c->stage = ST_ATTEMPT;
+}
+
+/* waterMainLoop body head, cpusolver.cpp:155-162 (Hold = H is an index copy) */
+__global__ void k_attempt_begin(Ctrl* c)
+{
+    if (c->stage != ST_ATTEMPT) return;
+    c->dt = dmin(c->dtCurr, c->maxTimeStep);
+    c->hold = c->cur;
+    c->best = -1;
+    c->bestMBR = NODATA_D;
+    c->approx = 0;
+    c->counters[0]++;
+    c->stage = ST_APPROX;
+}
+
+__device__ __forceinline__ void reject_attempt(Ctrl* c)     /* cpusolver.cpp:182-186 */
+{
+    c->cur = c->hold;
+    c->best = -1;
+    c->stage = ST_ATTEMPT;
+}
+
+/* checkCourant, cpusolver.cpp:248-281, then the iteration budget of solver.h:55-59 */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_courant(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    const double cmax = reduce_partials_max(v.part0, v.nb);
+    if (threadIdx.x != 0) return;
+    c->counters[2]++;
+    c->courant = cmax;
+    if (cmax < 1.01 || c->dt <= c->dtMin) {
+        uint32_t budget = (uint32_t)((c->approx + 1) * ((float)c->maxIter / (float)c->maxApprox));
+        c->iterBudget = budget > 25u ? budget : 25u;
+        c->iter = 0;
+        c->bestNorm = 1.;
+        c->linearValid = 1;
+        c->stage = ST_SWEEP;
+        return;
+    }
+    double d = c->dtCurr / cmax;
+    int mult = 0;
+    while (d < 1.) { d *= 10.; ++mult; }
+    d = floor(d);
+    for (int k = 0; k < mult; ++k) d /= 10.;
+    c->dtCurr = dmax(c->dtMin, d);
+    c->counters[4]++;
+    reject_attempt(c);
+}
+
+/* solveLinearSystem loop control, cpusolver.cpp:672-703 + :442-447 */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP) return;
+    const double sum = reduce_partials_sum(v.part0, v.nb);
+    if (threadIdx.x != 0) return;
+    const double norm = sum / v.N;
+    c->cur = free_buffer(c);          /* std::swap(vectorNewX, vectorX), water.cpp:598 */
+    c->iter++;
+    c->counters[3]++;
+    c->lastNorm = norm;
+    bool done = false, valid = true;
+    if (norm < c->residualTolerance) done = true;
+    else if (norm > (c->bestNorm * 10)) { done = true; valid = false; }
+    else {
+        if (norm < c->bestNorm) c->bestNorm = norm;
+        if (c->iter >= c->iterBudget) done = true;
+    }
+    if (!done) return;
+    c->linearValid = valid ? 1 : 0;
+    if (!valid) c->counters[5]++;
+    if (!valid && c->dt > c->dtMin) {
+        c->dtCurr = dmax(c->dtMin, c->dtCurr / 2.);
+        reject_attempt(c);
+    } else
+        c->stage = ST_POST;
+}
+
+/* computeCurrentMassBalance, water.cpp:96-123 */
+__device__ __forceinline__ void mass_balance(Ctrl* c, double storage, double sink)
+{
+    BalanceDev b;
+    b.storage = storage;
+    const double dS = b.storage - c->prevStep.storage;
+    b.sinkSource = sink;
+    b.MBE = dS - b.sinkSource;
+    const double timePct = 0.001 * dmax(c->dt, 30.0) / 3600.;
+    double minRef = b.storage * timePct;
+    minRef = dmax(minRef, 0.001);
+    const double ref = dmax(fabs(b.sinkSource), minRef);
+    b.MBR = b.MBE / ref;
+    c->curStep = b;
+}
+/* scalar part of acceptStep, water.cpp:233-237 */
+__device__ __forceinline__ void accept_bookkeeping(Ctrl* c)
+{
+    c->prevStep.storage = c->curStep.storage;
+    c->prevStep.sinkSource = c->curStep.sinkSource;
+    c->curPeriod.sinkSource += c->curStep.sinkSource;
+    c->stage = ST_ACCEPT;
+}
+__device__ __forceinline__ void halve_and_reject(Ctrl* c)
+{
+    c->dtCurr = dmax(c->dtCurr * 0.5, c->dtMin);
+    reject_attempt(c);
+}
+
+/* evaluateWaterBalance, water.cpp:165-227 */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_balance(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_POST) return;
+    const double storage = reduce_partials_sum(v.part0, v.nb);
+    const double sink = reduce_partials_sum(v.part1, v.nb);
+    if (threadIdx.x != 0) return;
+    c->counters[7]++;
+    mass_balance(c, storage, sink);
+    const double err = fabs(c->curStep.MBR);
+    const uint32_t approx = c->approx;
+    if (isnan(err)) {
+        if (c->dt > c->dtMin) halve_and_reject(c);
+        else if (approx > 0) { c->cur = c->best; c->stage = ST_RESTORE; }
+        else c->stage = ST_FAIL;
+        return;
+    }
+    if (err < c->MBRThreshold) {
+        accept_bookkeeping(c);
+        if (approx < 3 && err < c->MBRThreshold * 0.1 && c->courant < c->courantThreshold)
+            c->dtCurr = dmin(c->dtMax, c->dtCurr * 2);
+        return;
+    }
+    if (approx == 0 || err < c->bestMBR) { c->best = c->cur; c->bestMBR = err; }   /* keep-best = index copy */
+    if (err > (c->bestMBR * c->instabilityFactor) || approx == (c->maxApprox - 1)) {
+        if (c->dt > c->dtMin) { halve_and_reject(c); return; }
+        c->cur = c->best;                                                          /* restoreBestStep: H = Hbest */
+        c->stage = ST_RESTORE;
+        return;
+    }
+    c->approx = approx + 1;
+    c->stage = ST_APPROX;
+}
+
+/* tail of restoreBestStep (water.cpp:266) followed by acceptStep */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_restore(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_RESTORE) return;
+    const double storage = reduce_partials_sum(v.part0, v.nb);
+    const double sink = reduce_partials_sum(v.part1, v.nb);
+    if (threadIdx.x != 0) return;
+    c->counters[6]++;
+    mass_balance(c, storage, sink);
+    accept_bookkeeping(c);
+}
+
+__global__ void k_decide_accept(Ctrl* c)
+{
+    if (c->stage != ST_ACCEPT) return;
+    c->counters[1]++;
+    c->stage = ST_DONE;
+}
+
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
+{
+    const double storage = reduce_partials_sum(v.part0, v.nb);
+    if (threadIdx.x == 0) v.ctrl->query[0] = storage;
+}
+
+/* ======================================================================================= */
+/* node kernels (one thread per node)                                                       */
+/* ======================================================================================= */
+
+/* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
+ * updateBoundaryWaterData (water.cpp:632-807) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    if (i >= v.N) return;
+    const double H = v.X[c->cur][i], Ho = v.X[c->hold][i], z = v.z[i];
+    double K = 0.;
+    if (i >= v.ns) {
+        const SoilDev s = v.soils[v.cls[i]];
+        double Se;
+        if (c->approx == 0) { Se = node_se(s, H, z, c->wrc); v.Se[i] = Se; }
+        else Se = v.Se[i];
+        K = mualem_k(s, Se, c->wrc);
+        v.K[i] = K;
+        v.C[i] = v.size[i] * dtheta_dh(s, H, Ho, z, c->wrc);
+    }
+    boundary_update(v, c, i, H, Ho, z, K);
+}
+
+/* link conductances: water.cpp:300-343 dispatch, :413-487 runoff, :490-539 infiltration,
+ * :542-562 redistribution */
+__device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t slot,
+                                                   uint8_t kind, const double* __restrict__ Xc,
+                                                   const double* __restrict__ Xh, double Hi, double Hoi,
+                                                   double zi, double& courant)
+{
+    const size_t e = (size_t)slot * v.N + i;
+    const uint32_t j = v.lto[e];
+    const double area = v.larea[e], dist = v.ldist[e];
+    const double dt = c->dt;
+    if (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT) {
+        double ki = v.K[i], kj = v.K[j];
+        if (kind == LK_SOIL_LAT) { ki *= c->lvRatio; kj *= c->lvRatio; }
+        return (mean_of(ki, kj, c->meanType) * area) / dist;
+    }
+    if (kind == LK_RUNOFF) {
+        double Ha = 0.5 * (Hi + Hoi);
+        double Hb = 0.5 * (Xc[j] + Xh[j]);
+        if (c->approx == 0) {
+            const double fi = v.flow[i], fj = v.flow[j];
+            if (fi > 0) Ha += 0.5 * fi * dt / v.size[i];
+            if (fj > 0) Hb += 0.5 * fj * dt / v.size[j];
+        }
+        const double za = zi + v.pond[i], zb = v.z[j] + v.pond[j];
+        const double Hs = dmax(Ha, Hb) - dmax(za, zb);
+        if (Hs <= 0.00001) return 0.0;
+        if (dist <= 0.0) return 0.0;
+        const double rough = 0.5 * (v.roughness[v.cls[i]] + v.roughness[v.cls[j]]);
+        if (rough <= 0.0) return 0.0;
+        const double Aw = area * Hs;
+        const double Hs23 = cbrt(Hs * Hs);
+        const double Kij = Aw * Hs23 / (rough * dist);
+        const double dH = fabs(Ha - Hb);
+        const double slope = (dH > 0.00001) ? dH / dist : 0.0;
+        const double vel = Hs23 * sqrt(slope) / rough;
+        courant = dmax(courant, vel * dt / dist);
+        return Kij;
+    }
+    /* LK_INFILTRATION: one end is a surface node, the other a soil node */
+    const bool iSurf = i < v.ns;
+    const uint32_t su = iSurf ? i : j, so = iSurf ? j : i;
+    const double Hsu = iSurf ? Hi : Xc[j], Hosu = iSurf ? Hoi : Xh[j];
+    const double Hso = iSurf ? Xc[j] : Hi, Hoso = iSurf ? Xh[j] : Hoi;
+    const double zsu = iSurf ? zi : v.z[j];
+    const SoilDev s = v.soils[v.cls[so]];
+    double factor = 1.;
+    const uint8_t bt = v.btype[so];
+    if (bt == SF3D_BND_URBAN) factor = 0.33;
+    else if (bt == SF3D_BND_ROAD) return 0.;
+    if (Hso > zsu) return (s.Ksat * factor * area) / dist;
+    const double surfH = 0.5 * (Hsu + Hosu);
+    const double soilH = 0.5 * (Hso + Hoso);
+    double surfaceWater = dmax(surfH - zsu, 0.);
+    const double q = v.flow[su];
+    if (q < 0.) {
+        const double bm = (q * dt) / v.size[su];
+        surfaceWater = dmax(0., surfaceWater + bm);
+    }
+    const double maxInfRate = surfaceWater / dt;
+    if (maxInfRate < 2.78e-11) return 0.;
+    const double dH = dmax(surfH - soilH, 1e-12);
+    const double maxK = maxInfRate * (dist / dH);
+    const double meanK = mean_of(s.Ksat, v.K[so], c->meanType);
+    return (dmin(factor * meanK, maxK) * area) / dist;
+}
+
+/* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
+ * computeDiagonalElement (:335-345) + preconditioningMatrix (:284-305) + the Courant maximum */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_assemble(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    double courant = 0.;
+    if (i < v.N) {
+        const double* __restrict__ Xc = v.X[c->cur];
+        const double* __restrict__ Xh = v.X[c->hold];
+        const double Hi = Xc[i], Hoi = Xh[i], zi = v.z[i];
+        const double Ci = (i < v.ns) ? v.size[i] : v.C[i];       /* surface capacity = area, cpusolver.cpp:151 */
+        const double dt = c->dt;
+        constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+        double k[SF3D_SLOTS];
+        double sum = 0.;
+        #pragma unroll
+        for (int o = 0; o < SF3D_SLOTS; ++o) {
+            const uint32_t s = order[o];
+            const uint8_t kind = v.lkind[(size_t)s * v.N + i];
+            double ks = 0.;
+            if (kind != LK_NONE) ks = link_conductance(v, c, i, s, kind, Xc, Xh, Hi, Hoi, zi, courant);
+            k[s] = ks;
+            sum += ks;
+        }
+        const double cdt = Ci / dt;
+        const double inv = 1.0 / (cdt + sum);
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) v.A[(size_t)s * v.N + i] = (k[s] * -1.) * inv;
+        v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
+    }
+    const double bm = block_max(courant);
+    if (threadIdx.x == 0) v.part0[blockIdx.x] = bm;
+}
+
+/* JacobiWaterCPU, water.cpp:565-601 */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    double nrm = 0.;
+    if (i < v.N) {
+        const double* __restrict__ xin = v.X[c->cur];
+        double* __restrict__ xout = v.X[free_buffer(c)];
+        double xn = v.b[i];
+        constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+        #pragma unroll
+        for (int o = 0; o < SF3D_SLOTS; ++o) {
+            const size_t e = (size_t)order[o] * v.N + i;
+            const double a = v.A[e];
+            if (a != 0.) xn -= a * xin[v.lto[e]];
+        }
+        const double zi = v.z[i];
+        if (i < v.ns) xn = dmax(xn, zi);
+        nrm = fabs(xn - xin[i]);
+        const double psi = fabs(xn - zi);
+        if (psi > 1.) nrm *= (1. / psi);
+        xout[i] = xn;
+    }
+    const double bs = block_sum(nrm);
+    if (threadIdx.x == 0) v.part0[blockIdx.x] = bs;
+}
+
+__device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
+                                              double Se, double& st, double& sk)
+{
+    double theta;
+    if (i >= v.ns) {
+        const SoilDev s = v.soils[v.cls[i]];
+        theta = (Se * (s.thetaS - s.thetaR)) + s.thetaR;      /* soilPhysics.cpp:38-42 */
+    } else theta = dmax(H - z, 0.0);                          /* water.cpp:83 */
+    st = theta * v.size[i];
+    const double fl = v.flow[i];
+    sk = (fl != 0) ? fl * c->dt : 0.;                         /* water.cpp:136-137 */
+}
+
+/* cpusolver.cpp:451-457 (H = x is implicit: H is the current pool buffer) + the two sums of
+ * computeCurrentMassBalance (water.cpp:71-90, 130-140) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_POST) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    double st = 0., sk = 0.;
+    if (i < v.N) {
+        const double H = v.X[c->cur][i], z = v.z[i];
+        double Se = 1.;
+        if (i >= v.ns) { Se = node_se(v.soils[v.cls[i]], H, z, c->wrc); v.Se[i] = Se; }
+        balance_terms(v, c, i, H, z, Se, st, sk);
+    }
+    const double a = block_sum(st), b = block_sum(sk);
+    if (threadIdx.x == 0) { v.part0[blockIdx.x] = a; v.part1[blockIdx.x] = b; }
+}
+
+/* restoreBestStep, water.cpp:253-267 */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_RESTORE) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    double st = 0., sk = 0.;
+    if (i < v.N) {
+        const double H = v.X[c->cur][i], Ho = v.X[c->hold][i], z = v.z[i];
+        double Se = 1., K = 0.;
+        if (i >= v.ns) {
+            const SoilDev s = v.soils[v.cls[i]];
+            Se = node_se(s, H, z, c->wrc);
+            K = mualem_k(s, Se, c->wrc);
+            v.Se[i] = Se; v.K[i] = K;
+        }
+        boundary_update(v, c, i, H, Ho, z, K);
+        balance_terms(v, c, i, H, z, Se, st, sk);
+    }
+    const double a = block_sum(st), b = block_sum(sk);
+    if (threadIdx.x == 0) { v.part0[blockIdx.x] = a; v.part1[blockIdx.x] = b; }
+}
+
+/* acceptStep flow sums, water.cpp:240-250 + updateLinkFlux :269-277 (stored, row-normalised
+ * coefficient as in the reference; a zero coefficient adds exactly 0) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_ACCEPT) return;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    if (i >= v.N) return;
+    const double* __restrict__ X = v.X[c->cur];
+    const double Hi = X[i], dt = c->dt;
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) {
+        const size_t e = (size_t)s * v.N + i;
+        const double a = v.A[e];
+        if (a != 0. && v.lkind[e] != LK_NONE) v.lflowSum[e] += a * (Hi - X[v.lto[e]]) * dt;
+    }
+    if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
+}
+
+/* computeTotalWaterContent on the stored state (getTotalWaterContent / initializeBalance) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_storage(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    double st = 0.;
+    if (i < v.N) {
+        const double H = v.X[c->cur][i], z = v.z[i];
+        double theta;
+        if (i >= v.ns) { const SoilDev s = v.soils[v.cls[i]]; theta = (v.Se[i] * (s.thetaS - s.thetaR)) + s.thetaR; }
+        else theta = dmax(H - z, 0.0);
+        st = theta * v.size[i];
+    }
+    const double a = block_sum(st);
+    if (threadIdx.x == 0) v.part0[blockIdx.x] = a;
+}
+
+/* ======================================================================================= */
+/* host side                                                                                */
+/* ======================================================================================= */
+
+namespace {
+
+template <class F> void parallel_for(uint32_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 16) nt = 16;
+    if (n < 65536 || nt == 1) { f(0u, n); return; }
+    std::vector<std::thread> th;
+    const uint32_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint32_t a = t * chunk, b = (a + chunk < n) ? a + chunk : n;
+        if (a >= b) break;
+        th.emplace_back([=] { f(a, b); });
+    }
+    for (auto& t : th) t.join();
+}
+
+const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept"};
+
+}  // namespace
+
+struct DeviceSolver::Impl {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevView v{};
+    Ctrl* hostCtrl = nullptr;              /* pinned */
+    std::vector<void*> allocs;
+    uint32_t N = 0, ns = 0;
+    uint32_t lastSweeps = 8;
+    /* timing */
+    bool timing = false;
+    struct Pair { hipEvent_t a, b; int kid; };
+    std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
+    std::vector<hipEvent_t> freeEvents;
+    uint64_t launches[KID_COUNT] = {0};
+    double ms[KID_COUNT] = {0};
+};
+
+#define HIP_TRY(expr)                                                                          \
+    do { hipError_t e_ = (expr);                                                               \
+         if (e_ != hipSuccess) {                                                               \
+             snprintf(err_, sizeof(err_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+             return SF3D_SOLVER_ERROR; } } while (0)
+
+DeviceSolver& DeviceSolver::instance() { static DeviceSolver s; return s; }
+const char* DeviceSolver::kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kKernelNames[kid] : nullptr; }
+
+sf3d_error_t DeviceSolver::set_device(int dev)
+{
+    if (!impl_) impl_ = new Impl();
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (dev < 0 || dev >= count) { snprintf(err_, sizeof(err_), "device %d out of range (%d visible)", dev, count); return SF3D_SOLVER_ERROR; }
+    impl_->device = dev;
+    HIP_TRY(hipSetDevice(dev));
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::release()
+{
+    if (!impl_) return SF3D_OK;
+    Impl& I = *impl_;
+    if (I.stream) hipStreamSynchronize(I.stream);
+    for (auto& p : I.pending) { I.freeEvents.push_back(p.a); I.freeEvents.push_back(p.b); }
+    I.pending.clear();
+    for (void* p : I.allocs) hipFree(p);
+    I.allocs.clear();
+    built_ = false;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::synchronize()
+{
+    if (!impl_ || !impl_->stream) return SF3D_OK;
+    HIP_TRY(hipStreamSynchronize(impl_->stream));
+    return SF3D_OK;
+}
+
+template <class T> static hipError_t dev_alloc(std::vector<void*>& allocs, T*& p, size_t count)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+    if (e == hipSuccess) { allocs.push_back(q); p = static_cast<T*>(q); }
+    return e;
+}
+
+static void fill_params(Ctrl& c, const ParamsHost& p)
+{
+    c.MBRThreshold = p.MBRThreshold; c.residualTolerance = p.residualTolerance;
+    c.dtMin = p.dtMin; c.dtMax = p.dtMax; c.lvRatio = p.lvRatio;
+    c.courantThreshold = p.courantThreshold; c.instabilityFactor = p.instabilityFactor;
+    c.maxApprox = p.maxApprox; c.maxIter = p.maxIter; c.wrc = p.wrc; c.meanType = p.meanType;
+    c.dtCurr = p.dtCurr;
+}
+
+sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
+{
+    if (!impl_) impl_ = new Impl();
+    Impl& I = *impl_;
+    if (I.device < 0) {
+        int dev = 0;
+        if (const char* lr = getenv("LOCAL_RANK")) dev = atoi(lr);
+        int count = 0;
+        HIP_TRY(hipGetDeviceCount(&count));
+        if (count <= 0) { snprintf(err_, sizeof(err_), "no HIP device visible: the soilFluxes3D product path has no CPU fallback"); return SF3D_SOLVER_ERROR; }
+        I.device = dev % count;
+    }
+    HIP_TRY(hipSetDevice(I.device));
+    if (!I.stream) HIP_TRY(hipStreamCreateWithFlags(&I.stream, hipStreamNonBlocking));
+    if (!I.hostCtrl) HIP_TRY(hipHostMalloc((void**)&I.hostCtrl, sizeof(Ctrl), hipHostMallocDefault));
+
+    const uint32_t N = m.N, ns = m.ns;
+    const size_t NS = (size_t)N * SF3D_SLOTS;
+
+    if (m.graphDirty || !built_) {
+        /* the solver relies on surface nodes being exactly [0, ns) */
+        for (uint32_t i = 0; i < N; ++i) {
+            if ((m.surf[i] != 0) != (i < ns)) { snprintf(err_, sizeof(err_), "node %u: surface nodes must be exactly the first nrSurfaceNodes indices", i); return SF3D_TOPOGRAPHY_ERROR; }
+            if (!m.hasClass[i]) { snprintf(err_, sizeof(err_), "node %u has no soil/surface class", i); return SF3D_MISSING_DATA_ERROR; }
+        }
+        /* pull anything newer on the device before the arrays are re-created */
+        if (built_) { if (m.hostStaleState) fetch_state(m); if (m.hostStaleFlows) fetch_flows(m); }
+        release();
+        I.N = N; I.ns = ns;
+        DevView& v = I.v;
+        v = DevView{};
+        v.N = N; v.ns = ns; v.nb = (N + SF3D_BLOCK - 1) / SF3D_BLOCK;
+
+        /* derived static graph data: link kind and link distance (host, libm - exactly the
+         * reference's nodeDistance2D/3D arithmetic, soilPhysics.cpp:328-338) */
+        std::vector<uint8_t> kind(NS, LK_NONE);
+        std::vector<double> dist(NS, 0.), area(NS, 0.);
+        std::vector<uint32_t> to(NS, 0u);
+        bool bad = false;
+        parallel_for(N, [&](uint32_t a, uint32_t b) {
+            for (uint32_t i = a; i < b; ++i) {
+                const int nl = m.nLat[i];
+                for (int s = 0; s < SF3D_SLOTS; ++s) {
+                    if (s >= 2 && s - 2 >= nl) continue;            /* lateral loop bound, cpusolver.cpp:360 */
+                    if (m.ltype[s][i] == SF3D_LINK_NONE) continue;
+                    const uint32_t j = m.lto[s][i];
+                    const size_t e = (size_t)s * N + i;
+                    to[e] = j; area[e] = m.larea[s][i];
+                    const bool si = i >= ns, sj = j >= ns;
+                    if (si && sj) {
+                        if (m.ltype[s][i] == SF3D_LINK_LATERAL) {
+                            kind[e] = LK_SOIL_LAT;
+                            const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j], dz = m.z[i] - m.z[j];
+                            double nrm = 0; nrm += dx * dx; nrm += dy * dy; nrm += dz * dz;
+                            dist[e] = std::sqrt(nrm);
+                        } else { kind[e] = LK_SOIL_VERT; dist[e] = std::fabs(m.z[i] - m.z[j]); }
+                    } else if (!si && !sj) {
+                        kind[e] = LK_RUNOFF;
+                        const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j];
+                        double nrm = 0; nrm += dx * dx; nrm += dy * dy;
+                        dist[e] = std::sqrt(nrm);
+                    } else {
+                        kind[e] = LK_INFILTRATION;
+                        const uint32_t su = sj ? i : j, so = sj ? j : i;
+                        dist[e] = m.z[su] - m.z[so];
+                    }
+                }
+                if (m.btype[i] == SF3D_BND_FREE_DRAINAGE && m.ltype[0][i] == SF3D_LINK_NONE) bad = true;   /* assert water.cpp:682 */
+            }
+        });
+        if (bad) { snprintf(err_, sizeof(err_), "FreeDrainage node without an Up link"); return SF3D_BOUNDARY_ERROR; }
+
+        double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *larea, *ldist, *roughness;
+        uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils;
+        HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
+        HIP_TRY(dev_alloc(I.allocs, pond, N)); HIP_TRY(dev_alloc(I.allocs, sink, N));
+        HIP_TRY(dev_alloc(I.allocs, cls, N)); HIP_TRY(dev_alloc(I.allocs, btype, N));
+        HIP_TRY(dev_alloc(I.allocs, bslope, N)); HIP_TRY(dev_alloc(I.allocs, bsize, N));
+        HIP_TRY(dev_alloc(I.allocs, prescribed, N));
+        HIP_TRY(dev_alloc(I.allocs, lto, NS)); HIP_TRY(dev_alloc(I.allocs, lkind, NS));
+        HIP_TRY(dev_alloc(I.allocs, larea, NS)); HIP_TRY(dev_alloc(I.allocs, ldist, NS));
+        HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A, NS));
+        HIP_TRY(dev_alloc(I.allocs, v.b, N)); HIP_TRY(dev_alloc(I.allocs, v.C, N));
+        for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
+        HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N));
+        HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
+        HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
+        HIP_TRY(dev_alloc(I.allocs, v.part0, v.nb)); HIP_TRY(dev_alloc(I.allocs, v.part1, v.nb));
+        HIP_TRY(dev_alloc(I.allocs, soils, m.soils.size())); HIP_TRY(dev_alloc(I.allocs, roughness, m.roughness.size()));
+        HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
+        v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
+        v.bslope = bslope; v.bsize = bsize; v.prescribed = prescribed;
+        v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
+
+        std::vector<SoilDev> sd(m.soils.size());
+        for (size_t k = 0; k < sd.size(); ++k) {
+            const SoilHost& s = m.soils[k];
+            sd[k] = SoilDev{s.alpha, s.n, s.m, s.he, s.Sc, 1.0 / s.Sc, s.thetaS, s.thetaR, s.Ksat, s.L, 1.0 / s.m, s.mualemDen};
+        }
+        HIP_TRY(hipMemcpy(z, m.z.data(), N * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(size, m.size.data(), N * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(cls, m.cls.data(), N * 2, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lto, to.data(), NS * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lkind, kind.data(), NS, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(larea, area.data(), NS * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ldist, dist.data(), NS * 8, hipMemcpyHostToDevice));
+        if (!sd.empty()) HIP_TRY(hipMemcpy(soils, sd.data(), sd.size() * sizeof(SoilDev), hipMemcpyHostToDevice));
+        if (!m.roughness.empty()) HIP_TRY(hipMemcpy(roughness, m.roughness.data(), m.roughness.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(v.A, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
+        HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8));
+        for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(hipMemset(v.X[k], 0, N * 8));
+        HIP_TRY(hipDeviceSynchronize());      /* null-stream fills must land before the (non-blocking) solver stream runs */
+
+        std::memset(&mirror_, 0, sizeof(mirror_));
+        mirror_.cur = 0; mirror_.hold = 0; mirror_.best = -1; mirror_.stage = ST_IDLE;
+        mirror_.bestMBR = NODATA_D;
+        built_ = true;
+        m.graphDirty = false;
+        m.stateDirty = m.sinkDirty = m.pondDirty = m.boundaryDirty = m.flowSumsDirty = m.ctrlDirty = true;
+        m.hostStaleState = m.hostStaleFlows = false;
+    }
+
+    DevView& v = I.v;
+    if (m.stateDirty) {
+        HIP_TRY(hipMemcpyAsync(v.X[mirror_.cur], m.H.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        HIP_TRY(hipMemcpyAsync(v.Se, m.Se.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        HIP_TRY(hipMemcpyAsync(v.K, m.K.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        m.stateDirty = false;
+    }
+    if (m.sinkDirty) { HIP_TRY(hipMemcpyAsync((void*)v.sink, m.sink.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.sinkDirty = false; }
+    if (m.pondDirty) { HIP_TRY(hipMemcpyAsync((void*)v.pond, m.pond.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.pondDirty = false; }
+    if (m.boundaryDirty) {
+        HIP_TRY(hipMemcpyAsync((void*)v.btype, m.btype.data(), N, hipMemcpyHostToDevice, I.stream));
+        HIP_TRY(hipMemcpyAsync((void*)v.bslope, m.bslope.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        HIP_TRY(hipMemcpyAsync((void*)v.bsize, m.bsize.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        HIP_TRY(hipMemcpyAsync((void*)v.prescribed, m.prescribed.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        m.boundaryDirty = false;
+    }
+    if (m.flowSumsDirty) {
+        HIP_TRY(hipMemcpyAsync(v.bflowSum, m.bflowSum.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        for (int s = 0; s < SF3D_SLOTS; ++s)
+            HIP_TRY(hipMemcpyAsync(v.lflowSum + (size_t)s * N, m.lflowSum[s].data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        m.flowSumsDirty = false;
+    }
+    if (m.ctrlDirty || ctrlEdited_) {
+        fill_params(mirror_, p);
+        HIP_TRY(hipMemcpyAsync(v.ctrl, &mirror_, sizeof(Ctrl), hipMemcpyHostToDevice, I.stream));
+        m.ctrlDirty = false; ctrlEdited_ = false;
+    }
+    /* pageable-source async copies return once staged, but be explicit before host buffers change */
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::fetch_state(HostModel& m)
+{
+    Impl& I = *impl_;
+    HIP_TRY(hipMemcpyAsync(m.H.data(), I.v.X[mirror_.cur], (size_t)m.N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipMemcpyAsync(m.Se.data(), I.v.Se, (size_t)m.N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipMemcpyAsync(m.K.data(), I.v.K, (size_t)m.N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    /* the API reports Se = 1 and K = NODATA / 0 for surface nodes as the setters left them */
+    m.hostStaleState = false;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
+{
+    Impl& I = *impl_;
+    const size_t N = m.N;
+    HIP_TRY(hipMemcpyAsync(m.bflowSum.data(), I.v.bflowSum, N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipMemcpyAsync(m.bflowRate.data(), I.v.bflowRate, N * 8, hipMemcpyDeviceToHost, I.stream));
+    for (int s = 0; s < SF3D_SLOTS; ++s)
+        HIP_TRY(hipMemcpyAsync(m.lflowSum[s].data(), I.v.lflowSum + (size_t)s * N, N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    m.hostStaleFlows = false;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p, double* out)
+{
+    sf3d_error_t e = sync_to_device(m, p);
+    if (e != SF3D_OK) return e;
+    Impl& I = *impl_;
+    hipLaunchKernelGGL(k_storage, dim3(I.v.nb), dim3(SF3D_BLOCK), 0, I.stream, I.v);
+    hipLaunchKernelGGL(k_decide_query, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(I.hostCtrl, I.v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    mirror_ = *I.hostCtrl;
+    *out = mirror_.query[0];
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::timing(bool enable)
+{
+    if (!impl_) impl_ = new Impl();
+    impl_->timing = enable;
+    if (enable) { for (int k = 0; k < KID_COUNT; ++k) { impl_->launches[k] = 0; impl_->ms[k] = 0; } }
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::stats(int kid, uint64_t* launches, double* ms, uint64_t* nodes)
+{
+    if (!impl_ || kid < 0 || kid >= KID_COUNT) return SF3D_INDEX_ERROR;
+    *launches = impl_->launches[kid]; *ms = impl_->ms[kid]; *nodes = impl_->N;
+    return SF3D_OK;
+}
+
+/* One computeStep (soilFluxes3D.cpp:1785-1821 -> CPUSolver::run -> waterMainLoop).
+ * The host queues one approximation per batch - every kernel guarded by the device stage -
+ * and polls the control block once per batch. */
+sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep, double* dtOut)
+{
+    sf3d_error_t e = sync_to_device(m, p);
+    if (e != SF3D_OK) return e;
+    Impl& I = *impl_;
+    const DevView& v = I.v;
+    const dim3 grid(v.nb), block(SF3D_BLOCK), one(1);
+    hipStream_t st = I.stream;
+
+    auto timed = [&](int kid, auto launch) {
+        if (!I.timing) { launch(); return; }
+        hipEvent_t a, b;
+        if (I.freeEvents.size() >= 2) { a = I.freeEvents.back(); I.freeEvents.pop_back(); b = I.freeEvents.back(); I.freeEvents.pop_back(); }
+        else { hipEventCreate(&a); hipEventCreate(&b); }
+        hipEventRecord(a, st); launch(); hipEventRecord(b, st);
+        I.pending.push_back({a, b, kid});
+    };
+
+    hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
+    uint32_t stage = ST_ATTEMPT;
+    uint64_t before[8];
+    std::memcpy(before, mirror_.counters, sizeof(before));
+    int guard = 0;
+    while (true) {
+        if (stage == ST_ATTEMPT || stage == ST_APPROX) {
+            hipLaunchKernelGGL(k_attempt_begin, one, one, 0, st, v.ctrl);
+            timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props, grid, block, 0, st, v); });
+            timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL(k_assemble, grid, block, 0, st, v); });
+            hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
+        }
+        uint32_t chunk = I.lastSweeps + 2;
+        if (chunk < 4) chunk = 4;
+        if (chunk > 40) chunk = 40;
+        for (uint32_t k = 0; k < chunk; ++k) {
+            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep, grid, block, 0, st, v); });
+            hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
+        }
+        timed(KID_POST, [&] { hipLaunchKernelGGL(k_post, grid, block, 0, st, v); });
+        hipLaunchKernelGGL(k_decide_balance, one, block, 0, st, v);
+        timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore, grid, block, 0, st, v); });
+        hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
+        timed(KID_ACCEPT, [&] { hipLaunchKernelGGL(k_accept, grid, block, 0, st, v); });
+        hipLaunchKernelGGL(k_decide_accept, one, one, 0, st, v.ctrl);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const Ctrl& c = *I.hostCtrl;
+
+        if (I.timing) {
+            /* attribute event pairs only to launches that really ran (guarded no-ops excluded):
+             * executed counts per kernel come from the device counters */
+            uint64_t ran[KID_COUNT];
+            ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
+            ran[KID_SWEEP] = c.counters[3] - before[3];
+            ran[KID_POST] = c.counters[7] - before[7];
+            ran[KID_RESTORE] = c.counters[6] - before[6];
+            ran[KID_ACCEPT] = c.counters[1] - before[1];
+            for (auto& pr : I.pending) {
+                if (ran[pr.kid] > 0) {
+                    float t = 0.f;
+                    if (hipEventElapsedTime(&t, pr.a, pr.b) == hipSuccess) { I.ms[pr.kid] += t; I.launches[pr.kid]++; }
+                    ran[pr.kid]--;
+                }
+                I.freeEvents.push_back(pr.a); I.freeEvents.push_back(pr.b);
+            }
+            I.pending.clear();
+        }
+        std::memcpy(before, c.counters, sizeof(before));
+
+        stage = c.stage;
+        if (stage == ST_POST || stage == ST_DONE || stage == ST_FAIL || stage == ST_APPROX || stage == ST_ATTEMPT)
+            if (c.iter > 0) I.lastSweeps = c.iter;
+        if (stage == ST_DONE || stage == ST_FAIL) break;
+        if (++guard > 1000000) { snprintf(err_, sizeof(err_), "step state machine did not terminate (stage %u)", stage); return SF3D_SOLVER_ERROR; }
+    }
+    mirror_ = *I.hostCtrl;
+    p.dtCurr = mirror_.dtCurr;
+    *dtOut = mirror_.dt;
+    m.hostStaleState = true;
+    m.hostStaleFlows = true;
+    return (stage == ST_DONE) ? SF3D_OK : SF3D_SOLVER_ERROR;
+}

@@ -1,0 +1,135 @@
+"""Parity tests proper: the HIP product (through the C ABI) against the CPU oracle on the same
+inputs.  Tolerance is the one BASELINE.json's north_star states: node H and the cumulative mass
+balance within 1e-6 relative (fp64 path; transcendental functions of ROCm's ocml and glibc differ
+in the last ulp, the reductions are tree- instead of index-ordered)."""
+import numpy as np
+import pytest
+
+from criteria3d_amd import capi, catchment as cm
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # north_star: node H and cumulative mass balance within 1e-6 relative
+
+
+def rel(a, b, floor=1e-9):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
+def run_pair(product, oracle, model, forcing, hours, use_period=False):
+    """Yield (hour, product snapshot, oracle snapshot, product dts, oracle dts)."""
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_time_step(), "reset_time_step")
+        cm.build(sf, model, threads=1)
+    for h in range(hours):
+        mm = cm.FORCINGS[forcing](h)
+        out = []
+        for sf in (product, oracle):
+            steps, dts = cm.run_hour(sf, model, mm, use_period=use_period)
+            out.append((cm.snapshot(sf, model), dts))
+        yield h, out[0][0], out[1][0], out[0][1], out[1][1]
+
+
+def assert_snapshot_close(g, o, tag):
+    assert rel(g["H"], o["H"]) < RTOL, f"{tag}: H"
+    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6, f"{tag}: Se"
+    for k in ("total_water", "storage"):
+        assert abs(g[k] - o[k]) <= RTOL * abs(o[k]), f"{tag}: {k} {g[k]!r} vs {o[k]!r}"
+    for k in ("runoff", "drainage", "lateral"):
+        assert abs(g[k] - o[k]) <= RTOL * max(abs(o[k]), 1e-3), f"{tag}: {k} {g[k]!r} vs {o[k]!r}"
+
+
+def test_column_c1_24h(product, oracle):
+    """C1: 1-D column, 100 nodes, free drainage, constant rain, 24 h, via computeStep."""
+    m = cm.column_model()
+    for h, g, o, gd, od in run_pair(product, oracle, m, "R5", 24):
+        assert len(gd) == len(od), f"hour {h}: accepted steps {len(gd)} vs {len(od)}"
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+        assert_snapshot_close(g, o, f"C1 h{h}")
+    assert product.counters()["accepted"] == oracle.counters()["accepted"]
+
+
+def test_column_c1_compute_period_mbr(product, oracle):
+    """computePeriod updates the whole-period mass-balance ratio (water.cpp:143-156)."""
+    m = cm.column_model()
+    for h, g, o, _, _ in run_pair(product, oracle, m, "R5", 6, use_period=True):
+        assert_snapshot_close(g, o, f"C1p h{h}")
+        assert abs(g["mbr"] - o["mbr"]) <= 1e-6 * max(abs(o["mbr"]), 1e-3), (g["mbr"], o["mbr"])
+
+
+def test_catchment_c2_f20(product, oracle):
+    """C2: 64x64x10 tilted plane, 20 mm in hour 0 (infiltration regime), 6 h."""
+    m = cm.catchment_model(64, 64, 10)
+    steps = []
+    for h, g, o, gd, od in run_pair(product, oracle, m, "F20", 6):
+        assert len(gd) == len(od), f"hour {h}: accepted steps {len(gd)} vs {len(od)}"
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+        assert_snapshot_close(g, o, f"C2 F20 h{h}")
+        steps.append(len(gd))
+    assert steps == [22, 13, 6, 3, 3, 3]          # SURVEY.md 8c anchors
+    gc, oc = product.counters(), oracle.counters()
+    for k in ("attempts", "accepted", "approximations", "courant_rejections", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+
+
+def test_catchment_c2_f60_runoff_regime(product, oracle):
+    """C2 with 60 mm in hour 0: hour 0 (76 steps with Courant rejections) and the first 400
+    steps of hour 1, where dt is pinned at dtmin and every step ends through restoreBestStep."""
+    m = cm.catchment_model(64, 64, 10)
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        cm.build(sf, m, threads=1)
+    res = []
+    for sf in (product, oracle):
+        n0, d0 = cm.run_hour(sf, m, 60.0)
+        s0 = cm.snapshot(sf, m)
+        n1, d1 = cm.run_hour(sf, m, 0.0, max_steps=400)
+        res.append((n0, d0, s0, d1, cm.snapshot(sf, m), sf.counters()))
+    (gn0, gd0, gs0, gd1, gs1, gc), (on0, od0, os0, od1, os1, oc) = res
+    assert gn0 == on0 == 76
+    np.testing.assert_allclose(gd0, od0, rtol=1e-12)
+    assert_snapshot_close(gs0, os0, "C2 F60 h0")
+    np.testing.assert_allclose(gd1, od1, rtol=1e-12)
+    assert_snapshot_close(gs1, os1, "C2 F60 h1[:400]")
+    assert gc["restores"] == oc["restores"] and gc["restores"] > 300
+    assert gc["courant_rejections"] == oc["courant_rejections"] > 0
+
+
+def test_heterogeneous_soils(product, oracle):
+    """12 USDA classes in 8x8 patches (SURVEY.md 8d heterogeneous variant), small grid, 2 h."""
+    m = cm.catchment_model(32, 32, 6, heterogeneous=True)
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        cm.build(sf, m, threads=1)
+    for sf in (product, oracle):
+        cm.run_hour(sf, m, 20.0)
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    assert_snapshot_close(g, o, "het h0")
+    for sf in (product, oracle):
+        cm.run_hour(sf, m, 0.0, max_steps=300)
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    assert_snapshot_close(g, o, "het h1[:300]")
+
+
+def test_getters_and_state_setters_roundtrip(product, oracle):
+    """Per-node getters after device steps, and state setters between steps (hourly sinks,
+    daily pond, re-imposed potentials) reach the device."""
+    m = cm.catchment_model(16, 16, 5)
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        cm.build(sf, m, threads=1)
+        cm.run_hour(sf, m, 20.0)
+        # mid-run edits through the scalar API
+        sf.check(sf.lib.sf3d_set_node_matric_potential(m.ns + 5, -1.0), "set psi")
+        sf.check(sf.lib.sf3d_set_node_pond(3, 0.004), "set pond")
+        sf.check(sf.lib.sf3d_set_node_water_sink_source(m.ns + 40, -1e-7), "set sink")
+        sf.lib.sf3d_compute_step(600.0)
+    for i in (0, 3, m.ns + 5, m.ns + 40, m.n - 1):
+        for fn in ("get_node_total_potential", "get_node_matric_potential", "get_node_water_content",
+                   "get_node_degree_of_saturation", "get_node_water_conductivity"):
+            a, b = getattr(product, fn)(i), getattr(oracle, fn)(i)
+            assert abs(a - b) <= 1e-6 * max(abs(b), 1e-9), (fn, i, a, b)
+    a = product.boundary_water_flow(0, m.n); b = oracle.boundary_water_flow(0, m.n)
+    assert rel(a, b, floor=1e-6) < 1e-5
+    assert abs(product.get_total_water_content() - oracle.get_total_water_content()) < 1e-6 * oracle.get_total_water_content()
