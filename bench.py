@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py - simulated-hours per wall-second of the soilFluxes3D water time step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload C4|C3|C2] [--forcing F20|F60]
+
+A "step" is one simulated hour of the synthetic tilted-plane catchment of SURVEY.md 8d
+(default workload C4 = 512x512x20 nodes, forcing F20 = 20 mm of rain in hour 0): the hourly
+sink/source terms are set, then the caller's loop `while t < 3600: t += computeStep(3600 - t)`
+(src/project3D/project3D.cpp:1330-1359) runs on the HIP product through the C ABI.  W warm-up
+hours are run first and discarded (the model is then rebuilt from its initial state, outside the
+timed region); the K timed hours are hours 0..K-1 of the forcing.  Only the computeStep loops
+are timed, with the hour's sinks already resident in HBM (sf3d_synchronize() uploads them
+before the clock starts); a barrier + device synchronize brackets the timed region and the MAX
+over ranks is reported.  `value` = K simulated hours / that time.
+
+Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes per launch over
+its HIP-event duration measured on the solver's own stream) and `cpu_baseline` (rank 0, N=1:
+the unmodified reference built in oracle/_ref - or the oracle port when it cannot be loaded -
+on a bounded sample of the same workload, on the host cores of this box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20)}
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
+ALGO_BYTES = {"k_sweep": 152, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None):
+    """Run `hours` simulated hours; return wall seconds spent inside the computeStep loops."""
+    total = 0.0
+    for h in range(hours):
+        mm = cm.FORCINGS[forcing](h)
+        sf.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(mm, model.cell_area)))
+        sf.check(sf.lib.sf3d_synchronize(), "synchronize")          # inputs resident before the clock starts
+        t0 = time.perf_counter()
+        if hour_starts is not None:
+            hour_starts.append(t0)
+        t = 0.0
+        while t < 3600.0:
+            dt = sf.lib.sf3d_compute_step(3600.0 - t)
+            if not (dt > 0.0):
+                raise RuntimeError(f"compute_step returned {dt}")
+            t += dt
+            if per_step is not None:
+                per_step.append((time.perf_counter(), dt))
+        sf.check(sf.lib.sf3d_synchronize(), "synchronize")
+        total += time.perf_counter() - t0
+    return total
+
+
+def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0):
+    """Reference CPU/OpenMP path on a bounded sample: computeStep calls from the same initial
+    state until `budget_s` seconds of CPU work are spent (at least one step)."""
+    kind, sf = "port", None
+    try:
+        sf = capi.load_reference()
+        kind = "reference"
+    except Exception as e:  # noqa: BLE001  (missing Qt on the box, or oracle/_ref not built)
+        log(f"[bench] oracle/_ref not loadable ({e}); timing the oracle port instead")
+        sf = capi.load_oracle()
+    cores = os.cpu_count() or 1
+    if kind == "port":
+        sf.lib.sf3d_reset_solver_state()
+    t_build = time.perf_counter()
+    cm.build(sf, model, threads=cores)
+    cores = int(sf.lib.sf3d_set_threads_number(cores))
+    log(f"[bench] cpu_baseline: {kind} model built in {time.perf_counter() - t_build:.1f}s, {cores} threads")
+    sf.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(cm.FORCINGS[forcing](0), model.cell_area)))
+    sim, wall, nsteps = 0.0, 0.0, 0
+    while sim < 3600.0 and (wall < budget_s or nsteps == 0):
+        t0 = time.perf_counter()
+        dt = sf.lib.sf3d_compute_step(3600.0 - sim)
+        wall += time.perf_counter() - t0
+        if not (dt > 0.0):
+            break
+        sim += dt
+        nsteps += 1
+    sf.lib.sf3d_clean()
+    # the GPU's wall time for the SAME first nsteps steps of the same run
+    gpu_wall = None
+    if gpu_steps and nsteps >= 1 and len(gpu_steps[1]) >= nsteps:
+        gpu_wall = gpu_steps[1][nsteps - 1][0] - gpu_steps[0]      # end of step nsteps - start of hour 0
+    out = {"value": (sim / 3600.0) / wall if wall > 0 else None, "unit": "sim-h/s", "cores": cores, "kind": kind,
+           "sample": f"first {nsteps} computeStep calls ({sim:.0f} simulated s of hour 0) of {workload_name} {forcing}, "
+                     f"{wall:.1f} s wall"}
+    if gpu_wall:
+        out["gpu_same_sample_sim_h_per_s"] = (sim / 3600.0) / gpu_wall
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6, help="timed simulated hours")
+    ap.add_argument("--warmup", type=int, default=1, help="warm-up simulated hours (discarded)")
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            log(f"[bench] --gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
+            sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from criteria3d_amd import build, capi, catchment as cm
+
+    if not torch.cuda.is_available():
+        log("[bench] no GPU visible: the product path has no CPU fallback")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if rank == 0:
+        build.build_product()
+    if world > 1:
+        dist.barrier()
+    sf = capi.load_product()
+    sf.check(sf.lib.sf3d_set_device(local_rank), "set_device")
+
+    nx, ny, nz = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    model = cm.catchment_model(nx, ny, nz)
+    log(f"[bench] rank {rank}: {args.workload} model arrays in {time.perf_counter() - t0:.1f}s ({model.n} nodes)")
+
+    def fresh():
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, model, threads=1)
+        sf.check(sf.lib.sf3d_synchronize(), "synchronize")
+
+    t0 = time.perf_counter()
+    fresh()
+    log(f"[bench] rank {rank}: graph build + upload in {time.perf_counter() - t0:.1f}s")
+    if args.warmup > 0:
+        run_hours(sf, cm, model, args.forcing, args.warmup)
+        fresh()
+
+    sf.check(sf.lib.sf3d_kernel_timing(1), "kernel_timing")
+    per_step, hour_starts = [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    c0 = sf.counters()
+    elapsed = run_hours(sf, cm, model, args.forcing, args.steps, per_step=per_step, hour_starts=hour_starts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    c1 = sf.counters()
+    stats = sf.kernel_stats()
+    sf.lib.sf3d_kernel_timing(0)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    work = {k: c1[k] - c0[k] for k in c1}
+    # dominant kernel by measured device time
+    dom = max(stats, key=lambda k: stats[k][1]) if stats else None
+    roofline = None
+    if dom and stats[dom][0] > 0:
+        launches, ms, nodes = stats[dom]
+        avg_s = ms / 1e3 / launches
+        achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
+                    "kernels": {k: {"launches": v[0], "total_ms": v[1],
+                                    "GBps": (ALGO_BYTES[k] * v[2] * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
+                                for k, v in stats.items()}}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(cm, capi, model, args.forcing, args.workload,
+                               (hour_starts[0], per_step) if hour_starts else None, budget_s=args.cpu_budget)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cpu_baseline failed: {e}")
+
+    line = {
+        "metric": "simulated-hours/sec on 512x512x20 grid" if args.workload == "C4" else f"simulated-hours/sec on {nx}x{ny}x{nz} grid",
+        "value": args.steps / elapsed,
+        "unit": "sim-h/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} tilted-plane catchment (SURVEY.md 8d), forcing {args.forcing}, "
+                               f"{args.steps} simulated hours from the initial state",
+                   "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips",
+                   "work": work},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -537,14 +537,22 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
     return SF3D_OK;
 }
 double sf3d_get_time_step(void) { return P.dtCurr; }
-sf3d_error_t sf3d_reset_time_step(void) { P.dtCurr = SF3D_NODATA; M.ctrlDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_reset_solver_state(void) { P = ParamsHost(); M.ctrlDirty = true; return SF3D_OK; }
 sf3d_error_t sf3d_set_device(int d)
 {
     sf3d_error_t e = dev().set_device(d);
     if (e != SF3D_OK) fprintf(stderr, "sf3d: set_device: %s\n", dev().last_error());
     return e;
 }
-sf3d_error_t sf3d_synchronize(void) { return dev().synchronize(); }
+sf3d_error_t sf3d_synchronize(void)
+{
+    /* push every pending host edit (sinks, ponds, state, parameters) to the device, then drain the stream */
+    if (M.initialized && M.solverReady) {
+        sf3d_error_t e = dev().sync_to_device(M, P);
+        if (e != SF3D_OK) { fprintf(stderr, "sf3d: synchronize: %s\n", dev().last_error()); return e; }
+    }
+    return dev().synchronize();
+}
 sf3d_error_t sf3d_kernel_timing(int enable) { return dev().timing(enable != 0); }
 int sf3d_kernel_count(void) { return KID_COUNT; }
 const char* sf3d_kernel_name(int k) { return DeviceSolver::kernel_name(k); }

@@ -302,16 +302,20 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8]);
 
 /* current adaptive time step deltaTcurr [s] (Solver::getTimeStep, solver.h:36) */
 double sf3d_get_time_step(void);
-/* Forget the adaptive time step so that the next sf3d_initialize starts from deltaTmax as a
- * fresh process would (the reference keeps deltaTcurr across re-initialisations, SURVEY.md 8a
- * quirk 4; benchmarks need a reproducible start).  "reference" backend: SF3D_MISSING_DATA_ERROR. */
-sf3d_error_t sf3d_reset_time_step(void);
+/* Put every persistent solver parameter back to its fresh-process default (SolverParameters,
+ * types.h:291-315: deltaTcurr = NODATA -> deltaTmax at the next initialize, deltaTmax = 600, ...).
+ * The reference keeps them across re-initialisations (global CPUSolverObject, SURVEY.md 8a
+ * quirk 4), so two models run in one process influence each other; tests and benchmarks call
+ * this before sf3d_initialize to start exactly like a new process.
+ * "reference" backend: SF3D_MISSING_DATA_ERROR (not reachable through its public header). */
+sf3d_error_t sf3d_reset_solver_state(void);
 
 /* ---- device-side instrumentation (product backend only; others return MISSING_DATA) ------ */
 
 /* Select the HIP device for this process before sf3d_initialize (default: LOCAL_RANK or 0). */
 sf3d_error_t sf3d_set_device(int device);
-/* Block until all queued device work of the solver stream has finished. */
+/* Upload every pending host-side edit (sinks, ponds, state, parameters) to the device and block
+ * until all queued device work of the solver stream has finished. */
 sf3d_error_t sf3d_synchronize(void);
 /* Per-kernel HIP-event timing on the solver's own stream.  enable=1 starts recording an event
  * pair around every launch of the kernels listed by sf3d_kernel_name(); enable=0 stops. */

@@ -20,7 +20,7 @@ def rel(a, b, floor=1e-9):
 def run_pair(product, oracle, model, forcing, hours, use_period=False):
     """Yield (hour, product snapshot, oracle snapshot, product dts, oracle dts)."""
     for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_time_step(), "reset_time_step")
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset_solver_state")
         cm.build(sf, model, threads=1)
     for h in range(hours):
         mm = cm.FORCINGS[forcing](h)
@@ -55,7 +55,9 @@ def test_column_c1_compute_period_mbr(product, oracle):
     m = cm.column_model()
     for h, g, o, _, _ in run_pair(product, oracle, m, "R5", 6, use_period=True):
         assert_snapshot_close(g, o, f"C1p h{h}")
-        assert abs(g["mbr"] - o["mbr"]) <= 1e-6 * max(abs(o["mbr"]), 1e-3), (g["mbr"], o["mbr"])
+        # MBR = (delta storage - cumulative sink) / max(1 litre, sink): a difference of nearly equal
+        # numbers, so it is compared absolutely (it is judged against thresholds of 1e-3..1e-2)
+        assert abs(g["mbr"] - o["mbr"]) <= 1e-6, (g["mbr"], o["mbr"])
 
 
 def test_catchment_c2_f20(product, oracle):
@@ -78,7 +80,7 @@ def test_catchment_c2_f60_runoff_regime(product, oracle):
     steps of hour 1, where dt is pinned at dtmin and every step ends through restoreBestStep."""
     m = cm.catchment_model(64, 64, 10)
     for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
         cm.build(sf, m, threads=1)
     res = []
     for sf in (product, oracle):
@@ -100,7 +102,7 @@ def test_heterogeneous_soils(product, oracle):
     """12 USDA classes in 8x8 patches (SURVEY.md 8d heterogeneous variant), small grid, 2 h."""
     m = cm.catchment_model(32, 32, 6, heterogeneous=True)
     for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
         cm.build(sf, m, threads=1)
     for sf in (product, oracle):
         cm.run_hour(sf, m, 20.0)
@@ -117,7 +119,7 @@ def test_getters_and_state_setters_roundtrip(product, oracle):
     daily pond, re-imposed potentials) reach the device."""
     m = cm.catchment_model(16, 16, 5)
     for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_time_step(), "reset")
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
         cm.build(sf, m, threads=1)
         cm.run_hour(sf, m, 20.0)
         # mid-run edits through the scalar API
