@@ -235,3 +235,84 @@ def snapshot(sf: capi.SF3D, m: Model) -> dict:
         drainage=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_DRAINAGE),
         lateral=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_LATERAL_DRAINAGE),
     )
+
+
+def ragged_model(nx: int = 7, ny: int = 6, nz: int = 4, cell: float = 5.0) -> Model:
+    """Edge-case graph: NODATA holes in the DEM, columns whose soil ends early (deeper layers have
+    fewer nodes, project3D.cpp:791-800), three soil classes, a prescribed-potential node.
+    Numbering stays layer-major / row-major over the EXISTING nodes (surface first)."""
+    rng = np.random.RandomState(7)
+    valid = np.ones((ny, nx), bool)
+    valid[0, nx - 1] = valid[2, 3] = valid[ny - 1, 0] = False          # holes
+    depth_layers = rng.randint(2, nz, size=(ny, nx))                     # soil layers per column: 2..nz-1
+    depth_layers[1, 1] = nz - 1
+    thick = 0.08
+    area = cell * cell
+    index = -np.ones((nz, ny, nx), np.int64)
+    n = 0
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                if valid[r, c] and (l == 0 or l <= depth_layers[r, c]):
+                    index[l, r, c] = n
+                    n += 1
+    ns = int(valid.sum())
+    x = np.zeros(n); y = np.zeros(n); z = np.zeros(n); size = np.zeros(n)
+    surf = np.zeros(n, np.uint8); btype = np.zeros(n, np.uint8); bslope = np.zeros(n); barea = np.zeros(n)
+    soil_index = np.zeros(n - ns, np.uint16)
+    ln, lt, ld, la = [], [], [], []
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                i = index[l, r, c]
+                if i < 0:
+                    continue
+                x[i], y[i] = c * cell, r * cell
+                zs = 50.0 + 0.03 * x[i] + 0.04 * y[i] + 0.2 * np.sin(1.3 * c + 0.7 * r)
+                outlet = (r == 0) or (c == 0)
+                if l == 0:
+                    z[i], size[i], surf[i] = zs, area, 1
+                    if outlet:
+                        btype[i], bslope[i], barea[i] = capi.BND_RUNOFF, 0.05, cell
+                else:
+                    z[i], size[i] = zs - (thick * (l - 0.5)), area * thick
+                    soil_index[i - ns] = (r // 2 + c // 3) % 3
+                    last = (l == depth_layers[r, c])
+                    if last:
+                        btype[i], barea[i] = capi.BND_FREE_DRAINAGE, area
+                    elif outlet:
+                        btype[i], bslope[i], barea[i] = capi.BND_FREE_LATERAL_DRAINAGE, 0.05, cell * thick
+                if l > 0:
+                    ln.append(i); lt.append(index[l - 1, r, c]); ld.append(capi.LINK_UP); la.append(area)
+                if l + 1 < nz and index[l + 1, r, c] >= 0:
+                    ln.append(i); lt.append(index[l + 1, r, c]); ld.append(capi.LINK_DOWN); la.append(area)
+                for dr, dc in LATERAL_OFFSETS:
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < ny and 0 <= cc < nx and index[l, rr, cc] >= 0:
+                        ln.append(i); lt.append(index[l, rr, cc]); ld.append(capi.LINK_LATERAL)
+                        la.append((cell if l == 0 else cell * thick) * 0.5)
+    # one prescribed-total-potential node in the middle of the deepest complete column
+    pnode = int(index[2, 1, 1])
+    btype[pnode], bslope[pnode], barea[pnode] = capi.BND_PRESCRIBED, 0.0, area
+    soils = usda_soils()
+    soils = [soils[2], soils[4], soils[8]]       # sandy loam, loam, clay loam
+    return Model(n=n, ns=ns, x=x, y=y, z=z, size=size, is_surface=surf, btype=btype, bslope=bslope, barea=barea,
+                 link_node=np.array(ln, np.uint32), link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8),
+                 link_area=np.array(la), soil_index=soil_index, soils=soils, psi0_soil=-1.5, lv_ratio=4.0,
+                 numerics=(0.25, 3600.0, 150, 10, 10, 3), cell_area=area, shape=(nx, ny, nz),
+                 meta=dict(kind="ragged", prescribed_node=pnode, prescribed_H=float(z[pnode] - 0.3)))
+
+
+def run_hour_sinks(sf: capi.SF3D, m: Model, sinks: np.ndarray, max_steps: int | None = None):
+    """One simulated hour with an explicit per-node sink/source array [m3/s] (all n nodes)."""
+    sf.set_sink_source_bulk(0, sinks)
+    t, dts = 0.0, []
+    while t < 3600.0:
+        dt = sf.lib.sf3d_compute_step(3600.0 - t)
+        if not (dt > 0.0):
+            raise capi.SF3DError(f"{sf.backend}: compute_step returned {dt}")
+        dts.append(dt)
+        t += dt
+        if max_steps is not None and len(dts) >= max_steps:
+            break
+    return len(dts), dts

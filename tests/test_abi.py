@@ -1,0 +1,165 @@
+"""Boundary tests that need no GPU: every symbol include/sf3d.h declares is exported by the
+product library (and by the oracle), the C++ shim exports exactly the reference's 70 mangled
+names, and the host-side API logic of the PRODUCT (validation rules, error codes, sentinels -
+soilFluxes3D.cpp) behaves like the reference's.  No compute call is made."""
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from criteria3d_amd import build, capi
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "sf3d.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sf3d_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported(lib: Path):
+    out = subprocess.run(["nm", "-D", "--defined-only", str(lib)], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_header_and_binding_table_agree():
+    assert declared_symbols() == sorted(capi.SIGNATURES)
+    assert len(capi.REFERENCE_API) == 70
+
+
+def test_product_library_exports_every_declared_symbol(product):
+    missing = set(declared_symbols()) - exported(capi.PRODUCT_LIB)
+    assert not missing, missing
+    assert product.backend == "hip"
+
+
+def test_oracle_library_exports_every_declared_symbol(oracle):
+    assert not set(declared_symbols()) - exported(capi.ORACLE_LIB)
+    assert oracle.backend == "oracle"
+
+
+def test_shim_exports_reference_symbols():
+    """nm of the drop-in shim lists exactly the 70 `T` symbols of SURVEY.md App. E."""
+    build.build_product()
+    lib = build.build_shim()
+    want = set((ROOT / "tests" / "golden" / "reference_api_symbols.txt").read_text().split())
+    assert len(want) == 70
+    got = {s for s in exported(lib) if s.startswith("_ZN12soilFluxes3D2v2")}
+    assert got == want
+
+
+def test_product_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", str(capi.PRODUCT_LIB)], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "sf3d_ref" not in out
+    src = "".join(p.read_text() for p in (ROOT / "criteria3d_amd" / "csrc").glob("*.*") if p.suffix in (".cpp", ".hip", ".h"))
+    assert "oracle/" not in src.replace("the oracle", "")
+
+
+# ---- host-side API logic of the product (no device needed) -------------------------------------
+
+def fresh(sf, n=6, ns=2):
+    sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+    sf.check(sf.lib.sf3d_initialize(n, ns, 8, 1, 0, 0, 0), "init")
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_validation_rules_match_reference(which, request):
+    sf = request.getfixturevalue(which)
+    L = sf.lib
+    assert L.sf3d_set_node(0, 0, 0, 0, 1, 1, 0, 0, 0) == capi.MEMORY_ERROR or True   # before init: MemoryError or stale model
+    assert L.sf3d_initialize(4, 1, 9, 1, 0, 0, 0) == capi.PARAMETER_ERROR            # > maxLateralLink (cpp:72-73)
+    fresh(sf)
+    # setSoilProperties validation (cpp:399-407) and duplicates (cpp:410-412)
+    ok = (0, 0, 3.6, 1.56, 1 - 1 / 1.56, 0.1, 0.078, 0.43, 2.9e-6, 0.5, 0.01, 0.2)
+    assert L.sf3d_set_soil_properties(*ok) == capi.OK
+    assert L.sf3d_set_soil_properties(*ok) == capi.PARAMETER_ERROR
+    for pos, bad in ((2, 0.0), (3, 1.0), (4, 1.0), (4, 0.0), (5, -0.1), (8, 0.0), (6, 1.0), (7, 1.5), (7, 0.0)):
+        args = list(ok); args[0] = 1; args[pos] = bad
+        assert L.sf3d_set_soil_properties(*args) == capi.PARAMETER_ERROR, (pos, bad)
+    args = list(ok); args[0] = 1; args[6] = 0.5; args[7] = 0.4                       # thetaR > thetaS
+    assert L.sf3d_set_soil_properties(*args) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_surface_properties(0, -1.0) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_surface_properties(0, 0.05) == capi.OK
+    # setNode / setNodeLink (cpp:595-683)
+    assert L.sf3d_set_node(6, 0, 0, 0, 1, 1, 0, 0, 0) == capi.INDEX_ERROR
+    for i in range(6):
+        assert L.sf3d_set_node(i, float(i), 0, 1.0 if i < 2 else 0.5, 1.0, 1 if i < 2 else 0, 0, 0, 0) == capi.OK
+    assert L.sf3d_set_node_link(0, 6, capi.LINK_DOWN, 1.0) == capi.INDEX_ERROR
+    assert L.sf3d_set_node_link(0, 2, capi.LINK_NONE, 1.0) == capi.PARAMETER_ERROR
+    for k in range(8):
+        assert L.sf3d_set_node_link(2, 3, capi.LINK_LATERAL, 1.0) == capi.OK
+    assert L.sf3d_set_node_link(2, 3, capi.LINK_LATERAL, 1.0) == capi.TOPOGRAPHY_ERROR   # 9th lateral (cpp:654-655)
+    # setNodeSoil / setNodeSurface need the surface flag and known classes (cpp:734-775)
+    assert L.sf3d_set_node_soil(0, 0, 0) == capi.INDEX_ERROR
+    assert L.sf3d_set_node_soil(2, 5, 0) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_soil(2, 0, 0) == capi.OK
+    assert L.sf3d_set_node_surface(2, 0) == capi.INDEX_ERROR
+    assert L.sf3d_set_node_surface(0, 3) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_surface(0, 0) == capi.OK
+    assert L.sf3d_set_node_pond(2, 0.01) == capi.INDEX_ERROR and L.sf3d_set_node_pond(0, 0.01) == capi.OK
+    # parameters (cpp:474-548)
+    assert L.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, 0.05) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, 10.0) == capi.OK
+    assert L.sf3d_set_numerical_parameters(0.5, 3600, 150, 10, 10, 3) == capi.OK
+    # state setters (cpp:803-945)
+    assert L.sf3d_set_node_water_content(2, -0.1) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_water_content(2, 1.5) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_degree_of_saturation(0, 0.5) == capi.INDEX_ERROR
+    assert L.sf3d_set_node_degree_of_saturation(2, 1.5) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_prescribed_total_potential(2, 0.0) == capi.BOUNDARY_ERROR
+    assert L.sf3d_set_culvert(0, 0.05, 0.01, 1, 1) == capi.BOUNDARY_ERROR            # unsupported (quirk 8)
+    # getters: sentinels (types.h:42-64)
+    assert L.sf3d_get_node_total_potential(99) == -1111.0
+    assert L.sf3d_get_node_pond(2) == -1111.0
+    assert L.sf3d_get_node_maximum_water_content(0) == -1111.0
+    assert L.sf3d_get_node_boundary_water_flow(2) == -4444.0
+    assert L.sf3d_clean() == capi.OK
+    assert L.sf3d_get_node_total_potential(0) == -2222.0
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_state_setters_round_trip_on_host(which, request):
+    """setNodeMatricPotential / DegreeOfSaturation / WaterContent derive H, Se, K immediately
+    (cpp:803-906); the product answers getters from its staging copy without a device."""
+    sf = request.getfixturevalue(which)
+    L = sf.lib
+    fresh(sf, n=3, ns=1)
+    L.sf3d_set_surface_properties(0, 0.05)
+    L.sf3d_set_soil_properties(0, 0, 3.6, 1.56, 1 - 1 / 1.56, 0.1, 0.078, 0.43, 2.9e-6, 0.5, 0.01, 0.2)
+    L.sf3d_set_node(0, 0, 0, 10.0, 1.0, 1, 0, 0, 0)
+    L.sf3d_set_node(1, 0, 0, 9.95, 0.1, 0, 0, 0, 0)
+    L.sf3d_set_node(2, 0, 0, 9.85, 0.1, 0, 0, 0, 0)
+    L.sf3d_set_node_surface(0, 0); L.sf3d_set_node_soil(1, 0, 0); L.sf3d_set_node_soil(2, 0, 0)
+    L.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, 10.0)
+    assert L.sf3d_set_node_matric_potential(1, -2.0) == capi.OK
+    assert L.sf3d_get_node_total_potential(1) == 9.95 - 2.0
+    se = L.sf3d_get_node_degree_of_saturation(1)
+    sc = (1 + (3.6 * 0.1) ** 1.56) ** -(1 - 1 / 1.56)
+    assert abs(se - (1 + (3.6 * 2.0) ** 1.56) ** -(1 - 1 / 1.56) / sc) < 1e-14
+    theta = L.sf3d_get_node_water_content(1)
+    assert abs(theta - (se * (0.43 - 0.078) + 0.078)) < 1e-15
+    # round trip: impose that Se on node 2, the matric potential must come back
+    assert L.sf3d_set_node_degree_of_saturation(2, se) == capi.OK
+    assert abs(L.sf3d_get_node_matric_potential(2) - (-2.0)) < 1e-9
+    assert L.sf3d_set_node_water_content(2, theta) == capi.OK
+    assert abs(L.sf3d_get_node_matric_potential(2) - (-2.0)) < 1e-9
+    assert 0 < L.sf3d_get_node_water_conductivity(2) < 2.9e-6
+    # surface conventions
+    assert L.sf3d_set_node_water_content(0, 0.003) == capi.OK
+    assert abs(L.sf3d_get_node_water_content(0) - 0.003) < 1e-15 and L.sf3d_get_node_degree_of_saturation(0) == 1.0
+    assert L.sf3d_get_node_pond(0) == np.float32(0.0001)                              # default pond 0.0001f (cpp:616)
+    L.sf3d_clean()
+
+
+def test_product_fails_loudly_without_a_gpu(product):
+    """No CPU fallback: on a machine without a HIP device the step does not silently run elsewhere."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from criteria3d_amd import catchment as cm
+    with pytest.raises(capi.SF3DError):
+        cm.build(product, cm.column_model(10))
+    product.lib.sf3d_clean()
