@@ -135,7 +135,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    if rank == 0:
+    if rank == 0 and not os.environ.get("SF3D_PRODUCT_LIB"):
         build.build_product()
     if world > 1:
         dist.barrier()

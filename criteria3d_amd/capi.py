@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-PRODUCT_LIB = ROOT / "criteria3d_amd" / "csrc" / "libsf3d_hip.so"
+PRODUCT_LIB = Path(os.environ.get("SF3D_PRODUCT_LIB", ROOT / "criteria3d_amd" / "csrc" / "libsf3d_hip.so"))
 ORACLE_LIB = ROOT / "oracle" / "libsf3d_oracle.so"
 REFERENCE_LIB = ROOT / "oracle" / "_ref" / "libsf3d_ref.so"
 QT_CORE = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))

@@ -7,7 +7,8 @@
  *   static graph   lto[10][N] u32, lkind[10][N] u8, larea[10][N], ldist[10][N]  (slot-major:
  *                  slot 0 Up, 1 Down, 2..9 laterals; consecutive threads read consecutive
  *                  nodes of one slot => coalesced), z, size, pond, cls u16, btype u8,
- *                  bslope, bsize, prescribed
+ *                  bslope, bsize, prescribed; per (64-node chunk, slot) descriptors ckind/cdelta
+ *                  that replace lto/lkind reads wherever the numbering is locally regular
  *   soil classes   SoilDev[] (gathered by cls, L2/scalar-cache resident)
  *   state          X[4][N]: pool of head buffers; H, Hold and Hbest are INDICES into the
  *                  pool kept in Ctrl (no copies on step begin / reject / keep-best / restore)
@@ -24,6 +25,10 @@
 #define SF3D_SLOTS 10
 #define SF3D_POOL 4
 #define SF3D_BLOCK 256
+#define SF3D_CHUNK 64            /* one wave64 = 64 consecutive nodes */
+#define SF3D_MAX_BLOCKS 2048     /* 8 blocks of 256 threads per CU x 256 CUs */
+#define CK_NONE 0                /* chunk descriptor: no node of the chunk has this link slot        */
+#define CK_MIXED 255             /* chunk descriptor: per-node lkind/lto must be read                 */
 
 /* link kinds (derived once per graph change from the two end nodes, water.cpp:308-324) */
 enum : uint8_t { LK_NONE = 0, LK_SOIL_VERT = 1, LK_SOIL_LAT = 2, LK_RUNOFF = 3, LK_INFILTRATION = 4 };
@@ -43,6 +48,14 @@ enum : uint32_t {
 
 struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
+};
+
+/* per-chunk link descriptor, 64 bytes so a wave fetches it with one s_load_dwordx16 */
+struct ChunkDesc {
+    int32_t delta[SF3D_SLOTS];          /* j - i when kind[s] is a uniform link kind, else 0 */
+    uint8_t kind[SF3D_SLOTS];           /* CK_NONE | LK_* (uniform) | CK_MIXED */
+    uint8_t rowType;                    /* 0 all surface nodes, 1 all soil nodes, 2 straddles nrSurfaceNodes */
+    uint8_t pad[13];
 };
 
 struct BalanceDev { double storage, sinkSource, MBE, MBR; };
@@ -73,6 +86,14 @@ struct Ctrl {
 
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
+    uint32_t nChunks;                   /* ceil(N / 64): one wave processes one chunk at a time */
+    uint32_t qSplit;                    /* chunks [0, qSplit) hold every surface node (runoff/infiltration rows, generic
+                                           assembly kernel); chunks [qSplit, nChunks) are soil-only */
+    uint32_t nbSurf, nbSoil;            /* grid sizes of the two assembly kernels */
+    /* per (chunk, slot): when every node of the chunk has the link with the same kind and the same
+     * index offset j - i, ckind = that kind and cdelta = that offset (no per-node index traffic);
+     * CK_NONE when no node has it (slot skipped); CK_MIXED otherwise */
+    const ChunkDesc* cdesc;             /* [nChunks], 64 B each: one scalar load per chunk */
     const double *z, *size, *pond, *sink;
     const uint16_t* cls;
     const uint8_t* btype;
@@ -84,7 +105,7 @@ struct DevView {
     double* A;                          /* [10][N] */
     double *b, *C;
     double* X[SF3D_POOL];
-    double *Se, *K, *flow, *bflowRate, *bflowSum;
+    double *Se, *SeHold, *K, *flow, *bflowRate, *bflowSum;   /* SeHold = Se(Hold), written at approximation 0 */
     double *part0, *part1;              /* per-block partials [nb] */
     const SoilDev* soils;
     const double* roughness;

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_courant(DevView v)
 {
     Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
-    const double cmax = reduce_partials_max(v.part0, v.nb);
+    const double cmax = reduce_partials_max(v.part0, v.nbSurf);
     if (threadIdx.x != 0) return;
     c->counters[2]++;
     c->courant = cmax;
@@ -369,8 +369,40 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
 }
 
 /* ======================================================================================= */
-/* node kernels (one thread per node)                                                       */
+/* node kernels: one wave64 walks 64-node chunks (grid-stride), one lane per node            */
 /* ======================================================================================= */
+
+/* chunk loop: q is wave-uniform (forced into an SGPR so descriptor loads go through the scalar path) */
+#define FOR_EACH_CHUNK_IN(q0, q1)                                                                 \
+    const uint32_t lane_ = threadIdx.x & 63u;                                                     \
+    const uint32_t wavesTotal_ = gridDim.x * (SF3D_BLOCK / 64);                                   \
+    for (uint32_t q = __builtin_amdgcn_readfirstlane((q0) + blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); \
+         q < (q1); q += wavesTotal_)
+#define FOR_EACH_CHUNK(v) FOR_EACH_CHUNK_IN(0u, (v).nChunks)
+
+/* dtheta/dH with the two saturation degrees already known (soilPhysics.cpp:224-279):
+ * Se(psiCurr) is the Se array (post-solve of the previous approximation, same H) and Se(psiPrev)
+ * is SeHold (written at approximation 0, when H == Hold) - the same values the reference
+ * recomputes with four pow calls per node per approximation. */
+__device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, double Ho, double z, uint32_t wrc,
+                                                   double SeCur, double SePrev)
+{
+    const double psiCurr = fabs(dmin(0.0, H - z));
+    const double psiPrev = fabs(dmin(0.0, Ho - z));
+    if (wrc == SF3D_WRC_VAN_GENUCHTEN) { if (psiCurr == 0.0 && psiPrev == 0.0) return 0.0; }
+    else if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) { if (psiCurr <= s.he && psiPrev <= s.he) return 0.0; }
+    double dSe;
+    if (fabs(psiCurr - psiPrev) < 1e-12) {
+        const double xx = s.alpha * psiCurr;
+        const double onePlus = 1. + pow(xx, s.n);
+        const double t1 = pow(onePlus, -(s.m + 1.));
+        const double t2 = pow(xx, s.n - 1.);
+        dSe = s.alpha * s.n * s.m * t1 * t2;
+        if (wrc == SF3D_WRC_MODIFIED_VAN_GENUCHTEN) dSe *= s.invSc;
+    } else
+        dSe = fabs((SeCur - SePrev) / (H - Ho));
+    return dSe * (s.thetaS - s.thetaR);
+}
 
 /* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
  * updateBoundaryWaterData (water.cpp:632-807) */
@@ -378,31 +410,69 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
-    if (i >= v.N) return;
-    const double H = v.X[c->cur][i], Ho = v.X[c->hold][i], z = v.z[i];
-    double K = 0.;
-    if (i >= v.ns) {
-        const SoilDev s = v.soils[v.cls[i]];
-        double Se;
-        if (c->approx == 0) { Se = node_se(s, H, z, c->wrc); v.Se[i] = Se; }
-        else Se = v.Se[i];
-        K = mualem_k(s, Se, c->wrc);
-        v.K[i] = K;
-        v.C[i] = v.size[i] * dtheta_dh(s, H, Ho, z, c->wrc);
+    const double* __restrict__ Xc = v.X[c->cur];
+    const double* __restrict__ Xh = v.X[c->hold];
+    const uint32_t wrc = c->wrc;
+    const bool first = c->approx == 0;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double H = Xc[i], Ho = Xh[i], z = v.z[i];
+        double K = 0.;
+        if (i >= v.ns) {
+            const SoilDev s = v.soils[v.cls[i]];
+            double Se, SeH;
+            if (first) { Se = node_se(s, H, z, wrc); SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se; }
+            else { Se = v.Se[i]; SeH = v.SeHold[i]; }
+            K = mualem_k(s, Se, wrc);
+            v.K[i] = K;
+            v.C[i] = v.size[i] * dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
+        }
+        boundary_update(v, c, i, H, Ho, z, K);
     }
-    boundary_update(v, c, i, H, Ho, z, K);
+}
+
+/* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
+__device__ __forceinline__ double infiltration_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t j, size_t e,
+                                                           const double* __restrict__ Xc, const double* __restrict__ Xh,
+                                                           double Hi, double Hoi, double zi)
+{
+    const double area = v.larea[e], dist = v.ldist[e];
+    const double dt = c->dt;
+    const bool iSurf = i < v.ns;
+    const uint32_t su = iSurf ? i : j, so = iSurf ? j : i;
+    const double Hsu = iSurf ? Hi : Xc[j], Hosu = iSurf ? Hoi : Xh[j];
+    const double Hso = iSurf ? Xc[j] : Hi, Hoso = iSurf ? Xh[j] : Hoi;
+    const double zsu = iSurf ? zi : v.z[j];
+    const SoilDev s = v.soils[v.cls[so]];
+    double factor = 1.;
+    const uint8_t bt = v.btype[so];
+    if (bt == SF3D_BND_URBAN) factor = 0.33;
+    else if (bt == SF3D_BND_ROAD) return 0.;
+    if (Hso > zsu) return (s.Ksat * factor * area) / dist;
+    const double surfH = 0.5 * (Hsu + Hosu);
+    const double soilH = 0.5 * (Hso + Hoso);
+    double surfaceWater = dmax(surfH - zsu, 0.);
+    const double qf = v.flow[su];
+    if (qf < 0.) {
+        const double bm = (qf * dt) / v.size[su];
+        surfaceWater = dmax(0., surfaceWater + bm);
+    }
+    const double maxInfRate = surfaceWater / dt;
+    if (maxInfRate < 2.78e-11) return 0.;
+    const double dH = dmax(surfH - soilH, 1e-12);
+    const double maxK = maxInfRate * (dist / dH);
+    const double meanK = mean_of(s.Ksat, v.K[so], c->meanType);
+    return (dmin(factor * meanK, maxK) * area) / dist;
 }
 
 /* link conductances: water.cpp:300-343 dispatch, :413-487 runoff, :490-539 infiltration,
  * :542-562 redistribution */
-__device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t slot,
+__device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t j, size_t e,
                                                    uint8_t kind, const double* __restrict__ Xc,
                                                    const double* __restrict__ Xh, double Hi, double Hoi,
                                                    double zi, double& courant)
 {
-    const size_t e = (size_t)slot * v.N + i;
-    const uint32_t j = v.lto[e];
     const double area = v.larea[e], dist = v.ldist[e];
     const double dt = c->dt;
     if (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT) {
@@ -433,93 +503,160 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
         courant = dmax(courant, vel * dt / dist);
         return Kij;
     }
-    /* LK_INFILTRATION: one end is a surface node, the other a soil node */
-    const bool iSurf = i < v.ns;
-    const uint32_t su = iSurf ? i : j, so = iSurf ? j : i;
-    const double Hsu = iSurf ? Hi : Xc[j], Hosu = iSurf ? Hoi : Xh[j];
-    const double Hso = iSurf ? Xc[j] : Hi, Hoso = iSurf ? Xh[j] : Hoi;
-    const double zsu = iSurf ? zi : v.z[j];
-    const SoilDev s = v.soils[v.cls[so]];
-    double factor = 1.;
-    const uint8_t bt = v.btype[so];
-    if (bt == SF3D_BND_URBAN) factor = 0.33;
-    else if (bt == SF3D_BND_ROAD) return 0.;
-    if (Hso > zsu) return (s.Ksat * factor * area) / dist;
-    const double surfH = 0.5 * (Hsu + Hosu);
-    const double soilH = 0.5 * (Hso + Hoso);
-    double surfaceWater = dmax(surfH - zsu, 0.);
-    const double q = v.flow[su];
-    if (q < 0.) {
-        const double bm = (q * dt) / v.size[su];
-        surfaceWater = dmax(0., surfaceWater + bm);
-    }
-    const double maxInfRate = surfaceWater / dt;
-    if (maxInfRate < 2.78e-11) return 0.;
-    const double dH = dmax(surfH - soilH, 1e-12);
-    const double maxK = maxInfRate * (dist / dH);
-    const double meanK = mean_of(s.Ksat, v.K[so], c->meanType);
-    return (dmin(factor * meanK, maxK) * area) / dist;
+    return infiltration_conductance(v, c, i, j, e, Xc, Xh, Hi, Hoi, zi);
 }
 
 /* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
- * computeDiagonalElement (:335-345) + preconditioningMatrix (:284-305) + the Courant maximum */
-__global__ void __launch_bounds__(SF3D_BLOCK) k_assemble(DevView v)
+ * computeDiagonalElement (:335-345) + preconditioningMatrix (:284-305), in two kernels like the
+ * reference's two loops (surface rows, Courant check, soil rows - cpusolver.cpp:412-429). */
+__device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&k)[SF3D_SLOTS],
+                                          double sum, double Hoi, double dt)
+{
+    const double Ci = (i < v.ns) ? v.size[i] : v.C[i];            /* surface capacity = area, cpusolver.cpp:151 */
+    const double cdt = Ci / dt;
+    const double inv = 1.0 / (cdt + sum);
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s)
+        if (cd.kind[s] != CK_NONE) v.A[(size_t)s * v.N + i] = (k[s] * -1.) * inv;
+    v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
+}
+
+/* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
+ * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    const double* __restrict__ Xc = v.X[c->cur];
+    const double* __restrict__ Xh = v.X[c->hold];
+    const double dt = c->dt;
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     double courant = 0.;
-    if (i < v.N) {
-        const double* __restrict__ Xc = v.X[c->cur];
-        const double* __restrict__ Xh = v.X[c->hold];
+    FOR_EACH_CHUNK_IN(0u, v.qSplit) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const ChunkDesc cd = v.cdesc[q];
         const double Hi = Xc[i], Hoi = Xh[i], zi = v.z[i];
-        const double Ci = (i < v.ns) ? v.size[i] : v.C[i];       /* surface capacity = area, cpusolver.cpp:151 */
-        const double dt = c->dt;
-        constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
         double k[SF3D_SLOTS];
         double sum = 0.;
         #pragma unroll
         for (int o = 0; o < SF3D_SLOTS; ++o) {
             const uint32_t s = order[o];
-            const uint8_t kind = v.lkind[(size_t)s * v.N + i];
             double ks = 0.;
-            if (kind != LK_NONE) ks = link_conductance(v, c, i, s, kind, Xc, Xh, Hi, Hoi, zi, courant);
+            if (cd.kind[s] != CK_NONE) {
+                const size_t e = (size_t)s * v.N + i;
+                uint8_t kind; uint32_t j;
+                if (cd.kind[s] != CK_MIXED) { kind = cd.kind[s]; j = i + cd.delta[s]; }
+                else { kind = v.lkind[e]; j = v.lto[e]; }
+                if (kind != LK_NONE) ks = link_conductance(v, c, i, j, e, kind, Xc, Xh, Hi, Hoi, zi, courant);
+            }
             k[s] = ks;
             sum += ks;
         }
-        const double cdt = Ci / dt;
-        const double inv = 1.0 / (cdt + sum);
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) v.A[(size_t)s * v.N + i] = (k[s] * -1.) * inv;
-        v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
+        store_row(v, cd, i, k, sum, Hoi, dt);
     }
     const double bm = block_max(courant);
     if (threadIdx.x == 0) v.part0[blockIdx.x] = bm;
 }
 
-/* JacobiWaterCPU, water.cpp:565-601 */
+/* rows of the soil-only chunks [qSplit, nChunks).  Two groups of five slots: all index / area /
+ * distance loads and neighbour-K gathers of a group are issued before its first logarithm, so
+ * ~20 loads per lane overlap instead of forming dependent round trips (4 waves/SIMD). */
+#ifndef SF3D_ASM_WAVES
+#define SF3D_ASM_WAVES 4
+#endif
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    const double* __restrict__ Xc = v.X[c->cur];
+    const double* __restrict__ Xh = v.X[c->hold];
+    const double dt = c->dt, lvRatio = c->lvRatio;
+    const uint32_t meanType = c->meanType;
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    FOR_EACH_CHUNK_IN(v.qSplit, v.nChunks) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
+        const double Hoi = Xh[i], Ki = v.K[i];
+        double k[SF3D_SLOTS];
+        double sum = 0.;
+        #pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint32_t j[5]; uint8_t kd[5];
+            double area[5], dist[5], kj[5];
+            #pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const uint32_t s = order[g * 5 + t];
+                kd[t] = LK_NONE; j[t] = i; area[t] = 0.; dist[t] = 1.;
+                if (cd.kind[s] != CK_NONE) {
+                    const size_t e = (size_t)s * v.N + i;
+                    if (cd.kind[s] == CK_MIXED) { kd[t] = v.lkind[e]; j[t] = v.lto[e]; }
+                    else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
+                    area[t] = v.larea[e]; dist[t] = v.ldist[e];
+                }
+            }
+            #pragma unroll
+            for (int t = 0; t < 5; ++t) kj[t] = v.K[j[t]];
+            #pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const uint32_t s = order[g * 5 + t];
+                double ks = 0.;
+                if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
+                    const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
+                    ks = (mean_of(ki, kn, meanType) * area[t]) / dist[t];
+                } else if (kd[t] == LK_SOIL_VERT) {
+                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dist[t];
+                } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
+                    ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
+                }                                                            /* a soil row has no runoff link */
+                k[s] = ks;
+                sum += ks;
+            }
+        }
+        store_row(v, cd, i, k, sum, Hoi, dt);
+    }
+}
+
+/* JacobiWaterCPU, water.cpp:565-601.
+ * All coefficient loads, then all neighbour gathers, are issued before the ordered accumulation
+ * so that ~30 independent loads per lane are in flight (HBM-bound kernel, 152 algorithmic B/node). */
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_SWEEP) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    const double* __restrict__ xin = v.X[c->cur];
+    double* __restrict__ xout = v.X[free_buffer(c)];
+    const double* __restrict__ A = v.A;
     double nrm = 0.;
-    if (i < v.N) {
-        const double* __restrict__ xin = v.X[c->cur];
-        double* __restrict__ xout = v.X[free_buffer(c)];
-        double xn = v.b[i];
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        double a[SF3D_SLOTS], xj[SF3D_SLOTS];
+        uint32_t j[SF3D_SLOTS];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) a[s] = A[(size_t)s * v.N + i];
+        const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];   /* 0 for a missing link: in range */
+            else j[s] = i + cd.delta[s];                                     /* offset 0 when the slot is empty */
+        }
+        const double bi = v.b[i], zi = v.z[i], xi = xin[i];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
+        double xn = bi;
         constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
         #pragma unroll
         for (int o = 0; o < SF3D_SLOTS; ++o) {
-            const size_t e = (size_t)order[o] * v.N + i;
-            const double a = v.A[e];
-            if (a != 0.) xn -= a * xin[v.lto[e]];
+            const uint32_t s = order[o];
+            if (a[s] != 0.) xn -= a[s] * xj[s];                              /* zero entries are not in the reference's row */
         }
-        const double zi = v.z[i];
         if (i < v.ns) xn = dmax(xn, zi);
-        nrm = fabs(xn - xin[i]);
+        double d = fabs(xn - xi);
         const double psi = fabs(xn - zi);
-        if (psi > 1.) nrm *= (1. / psi);
+        if (psi > 1.) d *= (1. / psi);
+        nrm += d;
         xout[i] = xn;
     }
     const double bs = block_sum(nrm);
@@ -534,9 +671,9 @@ __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, u
         const SoilDev s = v.soils[v.cls[i]];
         theta = (Se * (s.thetaS - s.thetaR)) + s.thetaR;      /* soilPhysics.cpp:38-42 */
     } else theta = dmax(H - z, 0.0);                          /* water.cpp:83 */
-    st = theta * v.size[i];
+    st += theta * v.size[i];
     const double fl = v.flow[i];
-    sk = (fl != 0) ? fl * c->dt : 0.;                         /* water.cpp:136-137 */
+    if (fl != 0) sk += fl * c->dt;                            /* water.cpp:136-137 */
 }
 
 /* cpusolver.cpp:451-457 (H = x is implicit: H is the current pool buffer) + the two sums of
@@ -545,10 +682,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_POST) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    const double* __restrict__ Xc = v.X[c->cur];
     double st = 0., sk = 0.;
-    if (i < v.N) {
-        const double H = v.X[c->cur][i], z = v.z[i];
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double H = Xc[i], z = v.z[i];
         double Se = 1.;
         if (i >= v.ns) { Se = node_se(v.soils[v.cls[i]], H, z, c->wrc); v.Se[i] = Se; }
         balance_terms(v, c, i, H, z, Se, st, sk);
@@ -562,10 +701,13 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_RESTORE) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    const double* __restrict__ Xc = v.X[c->cur];
+    const double* __restrict__ Xh = v.X[c->hold];
     double st = 0., sk = 0.;
-    if (i < v.N) {
-        const double H = v.X[c->cur][i], Ho = v.X[c->hold][i], z = v.z[i];
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double H = Xc[i], Ho = Xh[i], z = v.z[i];
         double Se = 1., K = 0.;
         if (i >= v.ns) {
             const SoilDev s = v.soils[v.cls[i]];
@@ -586,31 +728,46 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_ACCEPT) return;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
-    if (i >= v.N) return;
     const double* __restrict__ X = v.X[c->cur];
-    const double Hi = X[i], dt = c->dt;
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) {
-        const size_t e = (size_t)s * v.N + i;
-        const double a = v.A[e];
-        if (a != 0. && v.lkind[e] != LK_NONE) v.lflowSum[e] += a * (Hi - X[v.lto[e]]) * dt;
+    const double* __restrict__ A = v.A;
+    const double dt = c->dt;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
+        uint32_t j[SF3D_SLOTS];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) a[s] = A[(size_t)s * v.N + i];      /* non-zero only where a link exists */
+        const ChunkDesc cd = v.cdesc[q];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
+            else j[s] = i + cd.delta[s];
+        }
+        const double Hi = X[i];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? v.lflowSum[(size_t)s * v.N + i] : 0.; }
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s)
+            if (a[s] != 0.) v.lflowSum[(size_t)s * v.N + i] = f[s] + a[s] * (Hi - xj[s]) * dt;
+        if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
     }
-    if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
 }
 
 /* computeTotalWaterContent on the stored state (getTotalWaterContent / initializeBalance) */
 __global__ void __launch_bounds__(SF3D_BLOCK) k_storage(DevView v)
 {
     const Ctrl* c = v.ctrl;
-    const uint32_t i = blockIdx.x * SF3D_BLOCK + threadIdx.x;
+    const double* __restrict__ Xc = v.X[c->cur];
     double st = 0.;
-    if (i < v.N) {
-        const double H = v.X[c->cur][i], z = v.z[i];
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double H = Xc[i], z = v.z[i];
         double theta;
         if (i >= v.ns) { const SoilDev s = v.soils[v.cls[i]]; theta = (v.Se[i] * (s.thetaS - s.thetaR)) + s.thetaR; }
         else theta = dmax(H - z, 0.0);
-        st = theta * v.size[i];
+        st += theta * v.size[i];
     }
     const double a = block_sum(st);
     if (threadIdx.x == 0) v.part0[blockIdx.x] = a;
@@ -747,7 +904,21 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         I.N = N; I.ns = ns;
         DevView& v = I.v;
         v = DevView{};
-        v.N = N; v.ns = ns; v.nb = (N + SF3D_BLOCK - 1) / SF3D_BLOCK;
+        v.N = N; v.ns = ns;
+        v.nChunks = (N + SF3D_CHUNK - 1) / SF3D_CHUNK;
+        v.nb = (v.nChunks + (SF3D_BLOCK / SF3D_CHUNK) - 1) / (SF3D_BLOCK / SF3D_CHUNK);
+        if (v.nb > SF3D_MAX_BLOCKS) v.nb = SF3D_MAX_BLOCKS;
+        if (v.nb == 0) v.nb = 1;
+        {
+            const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
+            v.qSplit = (ns + SF3D_CHUNK - 1) / SF3D_CHUNK;
+            if (v.qSplit > v.nChunks) v.qSplit = v.nChunks;
+            v.nbSurf = (v.qSplit + per - 1) / per;
+            if (v.nbSurf > SF3D_MAX_BLOCKS) v.nbSurf = SF3D_MAX_BLOCKS;
+            if (v.nbSurf == 0) v.nbSurf = 1;
+            v.nbSoil = (v.nChunks - v.qSplit + per - 1) / per;
+            if (v.nbSoil > SF3D_MAX_BLOCKS) v.nbSoil = SF3D_MAX_BLOCKS;
+        }
 
         /* derived static graph data: link kind and link distance (host, libm - exactly the
          * reference's nodeDistance2D/3D arithmetic, soilPhysics.cpp:328-338) */
@@ -788,8 +959,37 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         });
         if (bad) { snprintf(err_, sizeof(err_), "FreeDrainage node without an Up link"); return SF3D_BOUNDARY_ERROR; }
 
+        /* per (64-node chunk, slot) descriptors: uniform kind + uniform index offset => the kernels
+         * never read lto/lkind for that chunk and slot */
+        const uint32_t nChunks = v.nChunks;
+        std::vector<ChunkDesc> cdesc(nChunks);
+        parallel_for(nChunks, [&](uint32_t qa, uint32_t qb) {
+            for (uint32_t q = qa; q < qb; ++q) {
+                const uint32_t i0 = q * SF3D_CHUNK, i1 = (i0 + SF3D_CHUNK < N) ? i0 + SF3D_CHUNK : N;
+                ChunkDesc d;
+                std::memset(&d, 0, sizeof(d));
+                d.rowType = (i1 <= ns) ? 0 : (i0 >= ns ? 1 : 2);
+                for (int s = 0; s < SF3D_SLOTS; ++s) {
+                    bool any = false, all = true, same = true;
+                    uint8_t k0 = LK_NONE; int64_t d0 = 0;
+                    for (uint32_t i = i0; i < i1; ++i) {
+                        const size_t e = (size_t)s * N + i;
+                        if (kind[e] == LK_NONE) { all = false; continue; }
+                        const int64_t dd = (int64_t)to[e] - (int64_t)i;
+                        if (!any) { any = true; k0 = kind[e]; d0 = dd; }
+                        else if (kind[e] != k0 || dd != d0) same = false;
+                    }
+                    uint8_t ck = CK_NONE;
+                    if (any) ck = (all && same && d0 >= INT32_MIN && d0 <= INT32_MAX) ? k0 : (uint8_t)CK_MIXED;
+                    d.kind[s] = ck;
+                    d.delta[s] = (ck != CK_NONE && ck != CK_MIXED) ? (int32_t)d0 : 0;
+                }
+                cdesc[q] = d;
+            }
+        });
+
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *larea, *ldist, *roughness;
-        uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils;
+        uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
         HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
         HIP_TRY(dev_alloc(I.allocs, pond, N)); HIP_TRY(dev_alloc(I.allocs, sink, N));
         HIP_TRY(dev_alloc(I.allocs, cls, N)); HIP_TRY(dev_alloc(I.allocs, btype, N));
@@ -800,7 +1000,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A, NS));
         HIP_TRY(dev_alloc(I.allocs, v.b, N)); HIP_TRY(dev_alloc(I.allocs, v.C, N));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
-        HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N));
+        HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N)); HIP_TRY(dev_alloc(I.allocs, v.SeHold, N));
+        HIP_TRY(dev_alloc(I.allocs, dcdesc, (size_t)nChunks));
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
         HIP_TRY(dev_alloc(I.allocs, v.part0, v.nb)); HIP_TRY(dev_alloc(I.allocs, v.part1, v.nb));
@@ -809,6 +1010,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
         v.bslope = bslope; v.bsize = bsize; v.prescribed = prescribed;
         v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
+        v.cdesc = dcdesc;
 
         std::vector<SoilDev> sd(m.soils.size());
         for (size_t k = 0; k < sd.size(); ++k) {
@@ -822,10 +1024,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpy(lkind, kind.data(), NS, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(larea, area.data(), NS * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ldist, dist.data(), NS * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dcdesc, cdesc.data(), cdesc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
         if (!sd.empty()) HIP_TRY(hipMemcpy(soils, sd.data(), sd.size() * sizeof(SoilDev), hipMemcpyHostToDevice));
         if (!m.roughness.empty()) HIP_TRY(hipMemcpy(roughness, m.roughness.data(), m.roughness.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemset(v.A, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
-        HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8));
+        HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8)); HIP_TRY(hipMemset(v.SeHold, 0, N * 8));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(hipMemset(v.X[k], 0, N * 8));
         HIP_TRY(hipDeviceSynchronize());      /* null-stream fills must land before the (non-blocking) solver stream runs */
 
@@ -955,7 +1158,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (stage == ST_ATTEMPT || stage == ST_APPROX) {
             hipLaunchKernelGGL(k_attempt_begin, one, one, 0, st, v.ctrl);
             timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props, grid, block, 0, st, v); });
-            timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL(k_assemble, grid, block, 0, st, v); });
+            timed(KID_ASSEMBLE, [&] {
+                hipLaunchKernelGGL(k_assemble_surface, dim3(v.nbSurf), block, 0, st, v);
+                if (v.nbSoil) hipLaunchKernelGGL(k_assemble_soil, dim3(v.nbSoil), block, 0, st, v);
+            });
             hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
         }
         uint32_t chunk = I.lastSweeps + 2;
