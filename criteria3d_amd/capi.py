@@ -134,6 +134,12 @@ SIGNATURES = {
     "sf3d_kernel_count": (i32, []),
     "sf3d_kernel_name": (cstr, [i32]),
     "sf3d_kernel_stats": (u8, [i32, p64, pd, p64]),
+    "sf3d_dist_blob_bytes": (i32, []),
+    "sf3d_dist_prepare": (u8, [i32, i32]),
+    "sf3d_dist_export": (u8, [vp]),
+    "sf3d_dist_connect": (u8, [vp]),
+    "sf3d_dist_owner": (u8, [i32, u32, u32, C.POINTER(C.c_int32)]),
+    "sf3d_dist_halo": (u8, [i32, i32, i32, i32, u32, p32, p32]),
 }
 
 # the 70 entry points that stand in for soilFluxes3D.h:9-104 (everything before "extensions")
@@ -249,6 +255,31 @@ class SF3D:
         if code != OK:
             return None
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    # -- multi-GPU bootstrap -----------------------------------------------------------------
+    def dist_connect(self, rank, world, allgather):
+        """export this rank's window descriptor, all-gather the blobs with the launcher's control
+        plane, connect to the peers' windows"""
+        nbytes = self.lib.sf3d_dist_blob_bytes()
+        blob = C.create_string_buffer(nbytes)
+        self.check(self.lib.sf3d_dist_export(blob), "dist_export")
+        blobs = allgather(blob.raw)
+        assert len(blobs) == world and all(len(b) == nbytes for b in blobs)
+        joined = C.create_string_buffer(b"".join(blobs), nbytes * world)
+        self.check(self.lib.sf3d_dist_connect(joined), "dist_connect")
+
+    def owner_map(self, world, n):
+        out = np.empty(n, dtype=np.int32)
+        self.check(self.lib.sf3d_dist_owner(world, 0, n, out.ctypes.data_as(C.POINTER(C.c_int32))), "dist_owner")
+        return out
+
+    def halo_list(self, rank, world, peer, direction):
+        cnt = u32(0)
+        self.check(self.lib.sf3d_dist_halo(rank, world, peer, direction, 0, None, C.byref(cnt)), "dist_halo")
+        out = np.empty(cnt.value, dtype=np.uint32)
+        if cnt.value:
+            self.check(self.lib.sf3d_dist_halo(rank, world, peer, direction, cnt.value, _ptr(out, u32), C.byref(cnt)), "dist_halo")
+        return out
 
     def kernel_stats(self):
         """{kernel name: (launches, total_ms, nodes_per_launch)} from the HIP-event pool."""

@@ -168,12 +168,18 @@ def catchment_model(nx: int, ny: int, nz: int, heterogeneous: bool = False, cell
                  cell_area=area, shape=(nx, ny, nz), meta=dict(kind="catchment", heterogeneous=heterogeneous))
 
 
-def build(sf: capi.SF3D, m: Model, threads: int = 1):
-    """Push a Model through the ABI in the caller's order."""
+def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None):
+    """Push a Model through the ABI in the caller's order.
+
+    dist = (rank, world, allgather) shards the model over `world` ranks (HIP product only):
+    every rank pushes the same global model; `allgather(bytes) -> list[bytes]` is the launcher's
+    control-plane exchange (torch.distributed all_gather_object in bench.py and the tests)."""
+    if dist is not None:
+        rank, world, allgather = dist
+        sf.check(sf.lib.sf3d_dist_prepare(rank, world), "dist_prepare")
     sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
     sf.check(sf.lib.sf3d_set_surface_properties(0, m.roughness), "set_surface_properties")
     for k, s in enumerate(m.soils):
-        # soil number k+? : the catchment uses (soil=k, horizon=0)
         sf.check(sf.lib.sf3d_set_soil_properties(k, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"],
                                                  s["theta_r"], s["theta_s"], s["ksat"], s["L"],
                                                  s["organic_matter"], s["clay"]), "set_soil_properties")
@@ -190,6 +196,8 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1):
     psi = np.full(m.n, m.psi0_soil)
     psi[:m.ns] = m.psi0_surface
     sf.set_matric_potential_bulk(0, psi)
+    if dist is not None:
+        sf.dist_connect(dist[0], dist[1], dist[2])
     sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
 
 

@@ -553,6 +553,51 @@ sf3d_error_t sf3d_synchronize(void)
     }
     return dev().synchronize();
 }
+/* ---- multi-GPU ---- */
+int sf3d_dist_blob_bytes(void) { return (int)sizeof(DistBlob); }
+sf3d_error_t sf3d_dist_prepare(int rank, int world)
+{
+    sf3d_error_t e = dev().dist_prepare(rank, world);
+    if (e != SF3D_OK) fprintf(stderr, "sf3d: %s\n", dev().last_error());
+    return e;
+}
+sf3d_error_t sf3d_dist_export(void* blob)
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    sf3d_error_t e = dev().dist_export(M, P, static_cast<DistBlob*>(blob));
+    if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_export: %s\n", dev().last_error());
+    return e;
+}
+sf3d_error_t sf3d_dist_connect(const void* blobs)
+{
+    sf3d_error_t e = dev().dist_connect(static_cast<const DistBlob*>(blobs));
+    if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_connect: %s\n", dev().last_error());
+    return e;
+}
+/* partition queries are host logic: they work without a device */
+sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* out)
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    if ((uint64_t)first + count > M.N) return SF3D_INDEX_ERROR;
+    Partition part;
+    sf3d_error_t e = sf3d_compute_partition(M, 0, world, part);
+    if (e != SF3D_OK) return e;
+    for (uint32_t k = 0; k < count; ++k) out[k] = part.owner[first + k];
+    return SF3D_OK;
+}
+sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32_t capacity, uint32_t* out, uint32_t* count)
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    if (peer < 0 || peer >= world) return SF3D_PARAMETER_ERROR;
+    Partition part;
+    sf3d_error_t e = sf3d_compute_partition(M, rank, world, part);
+    if (e != SF3D_OK) return e;
+    const std::vector<uint32_t>& l = direction == 0 ? part.send[peer] : part.recv[peer];
+    *count = (uint32_t)l.size();
+    if (out) { if (capacity < l.size()) return SF3D_MEMORY_ERROR; std::copy(l.begin(), l.end(), out); }
+    return SF3D_OK;
+}
+
 sf3d_error_t sf3d_kernel_timing(int enable) { return dev().timing(enable != 0); }
 int sf3d_kernel_count(void) { return KID_COUNT; }
 const char* sf3d_kernel_name(int k) { return DeviceSolver::kernel_name(k); }

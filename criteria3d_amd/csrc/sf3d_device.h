@@ -76,6 +76,8 @@ struct Ctrl {
     uint32_t stage, approx, iter, iterBudget;
     int32_t cur, hold, best; /* indices into the X pool; best = -1 when none */
     uint32_t linearValid;
+    uint32_t epoch;         /* exchange counter, identical on every rank (multi-GPU) */
+    uint32_t distError;     /* 1 = a bounded wait for a peer expired */
     /* ---- balances (balanceData_t x4, soilFluxes3D.cpp:37) ---- */
     BalanceDev curStep, prevStep, curPeriod, wholePeriod;
     /* ---- query results (getTotalWaterContent etc.) ---- */
@@ -84,12 +86,41 @@ struct Ctrl {
     uint64_t counters[8];
 };
 
+/* ---- multi-GPU: one process per GPU, row strips of surface-cell columns --------
+ * Every rank holds full-size (global-index) arrays but computes only the chunks it owns.  Values a
+ * rank's rows read from a neighbouring strip (one-cell halo) are PUT by their owner into the
+ * reader's fine-grained, IPC-mapped window right after they are produced, then copied into the
+ * reader's own arrays by its next decision kernel, which also all-gathers the partial sums through
+ * the same windows (system-scope stores + epoch-stamped flags, double-buffered by epoch parity). */
+#define SF3D_MAX_RANKS 16
+struct DistMail { unsigned long long seq; double v[3]; };
+struct DistWindow {                     /* head of each rank's window; payload doubles follow */
+    DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
+};
+struct DistView {
+    int32_t world, rank;
+    DistWindow* win[SF3D_MAX_RANKS];    /* win[rank] = own window (local pointer), others IPC-mapped */
+    double* payload[SF3D_MAX_RANKS];    /* payload base of each rank's window */
+    /* what I send to peer p: node indices (device array), count, and where it lands in p's payload */
+    const uint32_t* sendIdx[SF3D_MAX_RANKS]; uint32_t sendCount[SF3D_MAX_RANKS]; uint64_t sendOff[SF3D_MAX_RANKS];
+    /* what I receive from peer p: node indices, count, offset in MY payload */
+    const uint32_t* recvIdx[SF3D_MAX_RANKS]; uint32_t recvCount[SF3D_MAX_RANKS]; uint64_t recvOff[SF3D_MAX_RANKS];
+    const uint8_t* owner;               /* [N] owning rank of each node (null when world == 1) */
+};
+/* payload layout per (receiver, source p): [parity 0/1][field 0/1][count] doubles at offset off[p] */
+
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
     uint32_t nChunks;                   /* ceil(N / 64): one wave processes one chunk at a time */
     uint32_t qSplit;                    /* chunks [0, qSplit) hold every surface node (runoff/infiltration rows, generic
                                            assembly kernel); chunks [qSplit, nChunks) are soil-only */
     uint32_t nbSurf, nbSoil;            /* grid sizes of the two assembly kernels */
+    /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
+     * [0, nListSurf) and its soil part [nListSurf, nList) */
+    const uint32_t* chunkList; uint32_t nList, nListSurf;
+    const DistView* dist;               /* device copy; null when world == 1 */
+    int32_t world, rank;
+    const uint8_t* owner;               /* = dist->owner, null when world == 1 */
     /* per (chunk, slot): when every node of the chunk has the link with the same kind and the same
      * index offset j - i, ckind = that kind and cdelta = that offset (no per-node index traffic);
      * CK_NONE when no node has it (slot skipped); CK_MIXED otherwise */

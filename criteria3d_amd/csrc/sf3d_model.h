@@ -58,6 +58,28 @@ struct HostModel {
     bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */
 };
 
+/* Row-strip partition of the node graph for `world` ranks (host logic, no device needed):
+ * a node belongs to the rank that owns its surface-cell column (the surface node reached by
+ * walking Up links); surface nodes [0, ns) are cut into `world` contiguous index ranges at
+ * multiples of 64.  send[p] / recv[p] are the sorted unique node lists exchanged with rank p
+ * (what p's rows read from my strip / what my rows read from p's strip). */
+struct Partition {
+    int world = 1, rank = 0;
+    std::vector<uint8_t> owner;                       /* [N] */
+    std::vector<uint32_t> bounds;                     /* [world + 1] surface-index strip bounds */
+    std::vector<std::vector<uint32_t>> send, recv;    /* [world] */
+};
+sf3d_error_t sf3d_compute_partition(const HostModel& m, int rank, int world, Partition& out);
+
+/* what each rank publishes to the others before the first step (sf3d_dist_export/connect) */
+struct DistBlob {
+    unsigned char ipcHandle[64];
+    uint64_t recvOff[SF3D_MAX_RANKS];
+    uint32_t recvCount[SF3D_MAX_RANKS];
+    uint32_t world, rank;
+    uint64_t nodes;
+};
+
 /* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR
  * and leave a message retrievable with last_error(). */
 class DeviceSolver {
@@ -78,6 +100,12 @@ public:
     void push_ctrl() { ctrlEdited_ = true; }
     bool ready() const { return built_; }
     const char* last_error() const { return err_; }
+    /* multi-GPU */
+    sf3d_error_t dist_prepare(int rank, int world);
+    sf3d_error_t dist_export(HostModel& m, const ParamsHost& p, DistBlob* out);
+    sf3d_error_t dist_connect(const DistBlob* all);
+    int world() const { return world_; }
+    int rank() const { return rank_; }
     /* instrumentation */
     sf3d_error_t timing(bool enable);
     sf3d_error_t stats(int kid, uint64_t* launches, double* ms, uint64_t* nodes);
@@ -89,6 +117,8 @@ private:
     Impl* impl_ = nullptr;
     Ctrl mirror_{};
     bool built_ = false, ctrlEdited_ = false;
+    int world_ = 1, rank_ = 0;
+    bool connected_ = false;
     char err_[256] = {0};
     friend struct Impl;
 };

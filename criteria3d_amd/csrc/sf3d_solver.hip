@@ -22,6 +22,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -192,6 +193,116 @@ __device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c,
 }
 
 /* ======================================================================================= */
+/* multi-GPU exchange (device side)                                                          */
+/* ======================================================================================= */
+
+#define SYS_STORE(p, x) __hip_atomic_store((p), (x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define SYS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+
+/* One block.  All-gather of up to three doubles per rank through the peers' windows, combined in
+ * rank order (identical bits on every rank).  op 0 = sum, 1 = max.  Advances the epoch.
+ * Returns false (and raises distError / ST_FAIL) when a peer does not answer within ~10 s. */
+__device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double (&vals)[3], int op)
+{
+    if (v.world <= 1) return true;
+    __shared__ double sh[3];
+    __shared__ int shOk;
+    if (threadIdx.x == 0) {
+        const DistView* d = v.dist;
+        const uint32_t e = c->epoch, par = e & 1u;
+        const unsigned long long tag = (unsigned long long)e + 1ull;
+        __threadfence_system();                  /* halo puts of the preceding kernels first */
+        for (int p = 0; p < v.world; ++p) {
+            DistMail* m = &d->win[p]->mail[par][v.rank];
+            SYS_STORE(&m->v[0], vals[0]); SYS_STORE(&m->v[1], vals[1]); SYS_STORE(&m->v[2], vals[2]);
+        }
+        __threadfence_system();
+        for (int p = 0; p < v.world; ++p)
+            __hip_atomic_store(&d->win[p]->mail[par][v.rank].seq, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        double acc[3] = {0., 0., 0.};
+        bool ok = true;
+        const long long t0 = wall_clock64();     /* 100 MHz */
+        for (int p = 0; p < v.world && ok; ++p) {
+            DistMail* m = &d->win[v.rank]->mail[par][p];
+            while (__hip_atomic_load(&m->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                __builtin_amdgcn_s_sleep(1);
+                if (wall_clock64() - t0 > 1000000000LL) { ok = false; break; }
+            }
+            if (!ok) break;
+            for (int k = 0; k < 3; ++k) {
+                const double x = SYS_LOAD(&m->v[k]);
+                if (p == 0) acc[k] = x;
+                else acc[k] = op ? dmax(acc[k], x) : acc[k] + x;
+            }
+        }
+        sh[0] = acc[0]; sh[1] = acc[1]; sh[2] = acc[2];
+        shOk = ok ? 1 : 0;
+        c->epoch = e + 1;
+        if (!ok) { c->distError = 1; c->stage = ST_FAIL; }
+    }
+    __syncthreads();
+    vals[0] = sh[0]; vals[1] = sh[1]; vals[2] = sh[2];
+    return shOk != 0;
+}
+
+/* whole block: copy field `field` of the payload every neighbour put for epoch parity `par` into dst */
+__device__ __forceinline__ void dist_unpack(const DevView& v, uint32_t par, int field, double* __restrict__ dst)
+{
+    const DistView* d = v.dist;
+    for (int p = 0; p < v.world; ++p) {
+        const uint32_t cnt = d->recvCount[p];
+        if (cnt == 0) continue;
+        const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * 2 + field) * cnt;
+        const uint32_t* idx = d->recvIdx[p];
+        for (uint32_t k = threadIdx.x; k < cnt; k += SF3D_BLOCK) dst[idx[k]] = SYS_LOAD(&src[k]);
+    }
+}
+
+/* grid-stride: put field values of my boundary nodes into every neighbour's window */
+__device__ __forceinline__ void dist_push(const DevView& v, uint32_t par, int field, const double* __restrict__ src)
+{
+    const DistView* d = v.dist;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int p = 0; p < v.world; ++p) {
+        const uint32_t cnt = d->sendCount[p];
+        if (cnt == 0) continue;
+        double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * 2 + field) * cnt;
+        const uint32_t* idx = d->sendIdx[p];
+        for (uint32_t k = tid; k < cnt; k += nth) SYS_STORE(&dst[k], src[idx[k]]);
+    }
+}
+
+/* after k_sweep: the new iterate of my boundary nodes -> neighbours (consumed by their k_decide_sweep) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_push_x(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP) return;
+    dist_push(v, c->epoch & 1u, 0, v.X[free_buffer(c)]);
+    __threadfence_system();
+}
+/* after k_props: K and waterFlow of my boundary nodes -> neighbours (consumed by their k_sync_kf) */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_push_kf(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    dist_push(v, c->epoch & 1u, 0, v.K);
+    dist_push(v, c->epoch & 1u, 1, v.flow);
+    __threadfence_system();
+}
+/* barrier + halo of K / waterFlow before the assembly reads neighbours */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_sync_kf(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    const uint32_t par = c->epoch & 1u;
+    __syncthreads();
+    double vals[3] = {0., 0., 0.};
+    if (!dist_allgather(v, c, vals, 0)) return;
+    dist_unpack(v, par, 0, v.K);
+    dist_unpack(v, par, 1, v.flow);
+}
+
+/* ======================================================================================= */
 /* control kernels (one thread / one block)                                                 */
 /* ======================================================================================= */
 
@@ -226,7 +337,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_courant(DevView v)
 {
     Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
-    const double cmax = reduce_partials_max(v.part0, v.nbSurf);
+    double vals[3] = {reduce_partials_max(v.part0, v.nbSurf), 0., 0.};
+    if (!dist_allgather(v, c, vals, 1)) return;
+    const double cmax = vals[0];
     if (threadIdx.x != 0) return;
     c->counters[2]++;
     c->courant = cmax;
@@ -254,10 +367,14 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
 {
     Ctrl* c = v.ctrl;
     if (c->stage != ST_SWEEP) return;
-    const double sum = reduce_partials_sum(v.part0, v.nb);
+    const int nxt = free_buffer(c);              /* the buffer k_sweep wrote */
+    const uint32_t par = c->epoch & 1u;
+    double vals[3] = {reduce_partials_sum(v.part0, v.nb), 0., 0.};
+    if (!dist_allgather(v, c, vals, 0)) return;
+    if (v.world > 1) dist_unpack(v, par, 0, v.X[nxt]);     /* neighbours' new iterate on my halo */
     if (threadIdx.x != 0) return;
-    const double norm = sum / v.N;
-    c->cur = free_buffer(c);          /* std::swap(vectorNewX, vectorX), water.cpp:598 */
+    const double norm = vals[0] / v.N;
+    c->cur = nxt;                     /* std::swap(vectorNewX, vectorX), water.cpp:598 */
     c->iter++;
     c->counters[3]++;
     c->lastNorm = norm;
@@ -312,8 +429,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_balance(DevView v)
 {
     Ctrl* c = v.ctrl;
     if (c->stage != ST_POST) return;
-    const double storage = reduce_partials_sum(v.part0, v.nb);
-    const double sink = reduce_partials_sum(v.part1, v.nb);
+    double vals[3] = {reduce_partials_sum(v.part0, v.nb), reduce_partials_sum(v.part1, v.nb), 0.};
+    if (!dist_allgather(v, c, vals, 0)) return;
+    const double storage = vals[0], sink = vals[1];
     if (threadIdx.x != 0) return;
     c->counters[7]++;
     mass_balance(c, storage, sink);
@@ -347,8 +465,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_restore(DevView v)
 {
     Ctrl* c = v.ctrl;
     if (c->stage != ST_RESTORE) return;
-    const double storage = reduce_partials_sum(v.part0, v.nb);
-    const double sink = reduce_partials_sum(v.part1, v.nb);
+    double vals[3] = {reduce_partials_sum(v.part0, v.nb), reduce_partials_sum(v.part1, v.nb), 0.};
+    if (!dist_allgather(v, c, vals, 0)) return;
+    const double storage = vals[0], sink = vals[1];
     if (threadIdx.x != 0) return;
     c->counters[6]++;
     mass_balance(c, storage, sink);
@@ -364,8 +483,9 @@ __global__ void k_decide_accept(Ctrl* c)
 
 __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
 {
-    const double storage = reduce_partials_sum(v.part0, v.nb);
-    if (threadIdx.x == 0) v.ctrl->query[0] = storage;
+    double vals[3] = {reduce_partials_sum(v.part0, v.nb), 0., 0.};
+    if (!dist_allgather(v, v.ctrl, vals, 0)) return;
+    if (threadIdx.x == 0) v.ctrl->query[0] = vals[0];
 }
 
 /* ======================================================================================= */
@@ -373,12 +493,17 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
 /* ======================================================================================= */
 
 /* chunk loop: q is wave-uniform (forced into an SGPR so descriptor loads go through the scalar path) */
-#define FOR_EACH_CHUNK_IN(q0, q1)                                                                 \
+#define FOR_EACH_CHUNK_IN(v, l0, l1)                                                              \
     const uint32_t lane_ = threadIdx.x & 63u;                                                     \
     const uint32_t wavesTotal_ = gridDim.x * (SF3D_BLOCK / 64);                                   \
-    for (uint32_t q = __builtin_amdgcn_readfirstlane((q0) + blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); \
-         q < (q1); q += wavesTotal_)
-#define FOR_EACH_CHUNK(v) FOR_EACH_CHUNK_IN(0u, (v).nChunks)
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane((l0) + blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); \
+         li_ < (l1); li_ += wavesTotal_)                                                          \
+        for (uint32_t q = __builtin_amdgcn_readfirstlane((v).chunkList[li_]), once_ = 1; once_; once_ = 0)
+/* chunks this rank owns (all of them on one GPU), their surface part, their soil part */
+#define FOR_EACH_CHUNK(v) FOR_EACH_CHUNK_IN(v, 0u, (v).nList)
+/* lane-level ownership: strips are cut at chunk boundaries whenever the numbering allows it, the
+ * per-node owner map covers the general case */
+#define NOT_MINE(v, i) ((i) >= (v).N || ((v).owner != nullptr && (v).owner[i] != (v).rank))
 
 /* dtheta/dH with the two saturation degrees already known (soilPhysics.cpp:224-279):
  * Se(psiCurr) is the Se array (post-solve of the previous approximation, same H) and Se(psiPrev)
@@ -416,7 +541,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
     const bool first = c->approx == 0;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const double H = Xc[i], Ho = Xh[i], z = v.z[i];
         double K = 0.;
         if (i >= v.ns) {
@@ -532,9 +657,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
     const double dt = c->dt;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     double courant = 0.;
-    FOR_EACH_CHUNK_IN(0u, v.qSplit) {
+    FOR_EACH_CHUNK_IN(v, 0u, v.nListSurf) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];
         const double Hi = Xc[i], Hoi = Xh[i], zi = v.z[i];
         double k[SF3D_SLOTS];
@@ -574,9 +699,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(De
     const double dt = c->dt, lvRatio = c->lvRatio;
     const uint32_t meanType = c->meanType;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-    FOR_EACH_CHUNK_IN(v.qSplit, v.nChunks) {
+    FOR_EACH_CHUNK_IN(v, v.nListSurf, v.nList) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
         const double Hoi = Xh[i], Ki = v.K[i];
         double k[SF3D_SLOTS];
@@ -631,7 +756,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     double nrm = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         double a[SF3D_SLOTS], xj[SF3D_SLOTS];
         uint32_t j[SF3D_SLOTS];
         #pragma unroll
@@ -686,7 +811,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
     double st = 0., sk = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const double H = Xc[i], z = v.z[i];
         double Se = 1.;
         if (i >= v.ns) { Se = node_se(v.soils[v.cls[i]], H, z, c->wrc); v.Se[i] = Se; }
@@ -706,7 +831,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     double st = 0., sk = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const double H = Xc[i], Ho = Xh[i], z = v.z[i];
         double Se = 1., K = 0.;
         if (i >= v.ns) {
@@ -733,7 +858,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     const double dt = c->dt;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
         uint32_t j[SF3D_SLOTS];
         #pragma unroll
@@ -762,7 +887,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_storage(DevView v)
     double st = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
+        if (NOT_MINE(v, i)) continue;
         const double H = Xc[i], z = v.z[i];
         double theta;
         if (i >= v.ns) { const SoilDev s = v.soils[v.cls[i]]; theta = (v.Se[i] * (s.thetaS - s.thetaR)) + s.thetaR; }
@@ -799,6 +924,61 @@ const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_po
 
 }  // namespace
 
+/* ---- row-strip partition (host logic; also used by CPU tests through sf3d_dist_owner/halo) ---- */
+sf3d_error_t sf3d_compute_partition(const HostModel& m, int rank, int world, Partition& out)
+{
+    const uint32_t N = m.N, ns = m.ns;
+    if (world < 1 || world > SF3D_MAX_RANKS || rank < 0 || rank >= world) return SF3D_PARAMETER_ERROR;
+    out.world = world; out.rank = rank;
+    out.owner.assign(N, 0);
+    out.bounds.assign(world + 1, 0);
+    out.send.assign(world, {}); out.recv.assign(world, {});
+    for (int r = 0; r <= world; ++r) {
+        uint64_t b = (uint64_t)ns * r / world;
+        if (r > 0 && r < world) b = (b / SF3D_CHUNK) * SF3D_CHUNK;      /* cut at chunk boundaries */
+        out.bounds[r] = (uint32_t)b;
+    }
+    out.bounds[world] = ns;
+    for (int r = 1; r <= world; ++r) if (out.bounds[r] < out.bounds[r - 1]) out.bounds[r] = out.bounds[r - 1];
+    if (world == 1) return SF3D_OK;
+    /* column id = surface ancestor through Up links (layer-major numbering: one pass suffices) */
+    std::vector<uint32_t> col(N, UINT32_MAX);
+    for (uint32_t i = 0; i < ns && i < N; ++i) col[i] = i;
+    for (int pass = 0; pass < 64; ++pass) {
+        bool changed = false, missing = false;
+        for (uint32_t i = ns; i < N; ++i) {
+            if (col[i] != UINT32_MAX) continue;
+            if (m.ltype[0][i] == SF3D_LINK_NONE) { col[i] = 0; changed = true; continue; }   /* orphan: rank 0 */
+            const uint32_t up = m.lto[0][i];
+            if (col[up] != UINT32_MAX) { col[i] = col[up]; changed = true; } else missing = true;
+        }
+        if (!missing || !changed) break;
+    }
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint32_t cidx = col[i] == UINT32_MAX ? 0u : col[i];
+        int r = 0;
+        while (r + 1 < world && cidx >= out.bounds[r + 1]) ++r;
+        out.owner[i] = (uint8_t)r;
+    }
+    for (int s = 0; s < SF3D_SLOTS; ++s)
+        for (uint32_t i = 0; i < N; ++i) {
+            if (m.ltype[s][i] == SF3D_LINK_NONE) continue;
+            if (s >= 2 && s - 2 >= m.nLat[i]) continue;
+            const uint32_t j = m.lto[s][i];
+            const int a = out.owner[i], b = out.owner[j];
+            if (a == b) continue;
+            if (a == rank) out.recv[b].push_back(j);       /* my row i reads node j of rank b */
+            if (b == rank) out.send[a].push_back(j);       /* rank a's row i reads my node j   */
+        }
+    for (int r = 0; r < world; ++r) {
+        for (auto* v : {&out.send[r], &out.recv[r]}) {
+            std::sort(v->begin(), v->end());
+            v->erase(std::unique(v->begin(), v->end()), v->end());
+        }
+    }
+    return SF3D_OK;
+}
+
 struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -807,6 +987,14 @@ struct DeviceSolver::Impl {
     std::vector<void*> allocs;
     uint32_t N = 0, ns = 0;
     uint32_t lastSweeps = 8;
+    /* multi-GPU */
+    Partition part;
+    DistWindow* window = nullptr;          /* fine-grained, IPC-exported */
+    size_t windowBytes = 0;
+    std::vector<void*> peerMaps;           /* hipIpcOpenMemHandle results */
+    DistView hostDist{};
+    DistView* devDist = nullptr;
+    uint32_t pushBlocks = 0;
     /* timing */
     bool timing = false;
     struct Pair { hipEvent_t a, b; int kid; };
@@ -845,6 +1033,11 @@ sf3d_error_t DeviceSolver::release()
     I.pending.clear();
     for (void* p : I.allocs) hipFree(p);
     I.allocs.clear();
+    for (void* p : I.peerMaps) hipIpcCloseMemHandle(p);
+    I.peerMaps.clear();
+    if (I.window) { hipFree(I.window); I.window = nullptr; }
+    I.devDist = nullptr;
+    connected_ = false;
     built_ = false;
     return SF3D_OK;
 }
@@ -898,6 +1091,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             if ((m.surf[i] != 0) != (i < ns)) { snprintf(err_, sizeof(err_), "node %u: surface nodes must be exactly the first nrSurfaceNodes indices", i); return SF3D_TOPOGRAPHY_ERROR; }
             if (!m.hasClass[i]) { snprintf(err_, sizeof(err_), "node %u has no soil/surface class", i); return SF3D_MISSING_DATA_ERROR; }
         }
+        if (world_ > 1 && connected_) { snprintf(err_, sizeof(err_), "topology changed after sf3d_dist_connect: export/connect again"); }
         /* pull anything newer on the device before the arrays are re-created */
         if (built_) { if (m.hostStaleState) fetch_state(m); if (m.hostStaleFlows) fetch_flows(m); }
         release();
@@ -906,19 +1100,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         v = DevView{};
         v.N = N; v.ns = ns;
         v.nChunks = (N + SF3D_CHUNK - 1) / SF3D_CHUNK;
-        v.nb = (v.nChunks + (SF3D_BLOCK / SF3D_CHUNK) - 1) / (SF3D_BLOCK / SF3D_CHUNK);
-        if (v.nb > SF3D_MAX_BLOCKS) v.nb = SF3D_MAX_BLOCKS;
-        if (v.nb == 0) v.nb = 1;
-        {
-            const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
-            v.qSplit = (ns + SF3D_CHUNK - 1) / SF3D_CHUNK;
-            if (v.qSplit > v.nChunks) v.qSplit = v.nChunks;
-            v.nbSurf = (v.qSplit + per - 1) / per;
-            if (v.nbSurf > SF3D_MAX_BLOCKS) v.nbSurf = SF3D_MAX_BLOCKS;
-            if (v.nbSurf == 0) v.nbSurf = 1;
-            v.nbSoil = (v.nChunks - v.qSplit + per - 1) / per;
-            if (v.nbSoil > SF3D_MAX_BLOCKS) v.nbSoil = SF3D_MAX_BLOCKS;
-        }
+        v.qSplit = (ns + SF3D_CHUNK - 1) / SF3D_CHUNK;
+        if (v.qSplit > v.nChunks) v.qSplit = v.nChunks;
 
         /* derived static graph data: link kind and link distance (host, libm - exactly the
          * reference's nodeDistance2D/3D arithmetic, soilPhysics.cpp:328-338) */
@@ -988,6 +1171,32 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             }
         });
 
+        /* ownership + chunk lists (identity lists on one GPU) */
+        {
+            sf3d_error_t pe = sf3d_compute_partition(m, rank_, world_, I.part);
+            if (pe != SF3D_OK) { snprintf(err_, sizeof(err_), "partition failed"); return pe; }
+        }
+        std::vector<uint32_t> listSurf, listSoil;
+        for (uint32_t q = 0; q < nChunks; ++q) {
+            bool mine = world_ == 1;
+            if (!mine) {
+                const uint32_t i0 = q * SF3D_CHUNK, i1 = (i0 + SF3D_CHUNK < N) ? i0 + SF3D_CHUNK : N;
+                for (uint32_t i = i0; i < i1 && !mine; ++i) mine = I.part.owner[i] == rank_;
+            }
+            if (mine) (q < v.qSplit ? listSurf : listSoil).push_back(q);
+        }
+        {
+            const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
+            v.nListSurf = (uint32_t)listSurf.size();
+            v.nList = (uint32_t)(listSurf.size() + listSoil.size());
+            auto blocks = [&](uint32_t chunks) { uint32_t b = (chunks + per - 1) / per; if (b > SF3D_MAX_BLOCKS) b = SF3D_MAX_BLOCKS; return b; };
+            v.nb = blocks(v.nList); if (v.nb == 0) v.nb = 1;
+            v.nbSurf = blocks(v.nListSurf); if (v.nbSurf == 0) v.nbSurf = 1;
+            v.nbSoil = blocks(v.nList - v.nListSurf);
+            v.world = world_; v.rank = rank_;
+        }
+        listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
+
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *larea, *ldist, *roughness;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
         HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
@@ -1002,6 +1211,44 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
         HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N)); HIP_TRY(dev_alloc(I.allocs, v.SeHold, N));
         HIP_TRY(dev_alloc(I.allocs, dcdesc, (size_t)nChunks));
+        uint32_t* dlist; HIP_TRY(dev_alloc(I.allocs, dlist, listSurf.size()));
+        if (!listSurf.empty()) HIP_TRY(hipMemcpy(dlist, listSurf.data(), listSurf.size() * 4, hipMemcpyHostToDevice));
+        v.chunkList = dlist;
+        v.owner = nullptr; v.dist = nullptr;
+        if (world_ > 1) {
+            uint8_t* downer; HIP_TRY(dev_alloc(I.allocs, downer, N));
+            HIP_TRY(hipMemcpy(downer, I.part.owner.data(), N, hipMemcpyHostToDevice));
+            v.owner = downer;
+            /* my window: mailboxes + payload areas for what each neighbour puts (2 parities x 2 fields) */
+            DistView& d = I.hostDist;
+            std::memset(&d, 0, sizeof(d));
+            d.world = world_; d.rank = rank_; d.owner = downer;
+            uint64_t off = 0;
+            uint32_t maxSend = 0;
+            for (int pr = 0; pr < world_; ++pr) {
+                d.recvCount[pr] = (uint32_t)I.part.recv[pr].size();
+                d.recvOff[pr] = off;
+                off += (uint64_t)d.recvCount[pr] * 4;
+                d.sendCount[pr] = (uint32_t)I.part.send[pr].size();
+                if (d.sendCount[pr] > maxSend) maxSend = d.sendCount[pr];
+                uint32_t *si, *ri;
+                HIP_TRY(dev_alloc(I.allocs, si, I.part.send[pr].size())); HIP_TRY(dev_alloc(I.allocs, ri, I.part.recv[pr].size()));
+                if (d.sendCount[pr]) HIP_TRY(hipMemcpy(si, I.part.send[pr].data(), (size_t)d.sendCount[pr] * 4, hipMemcpyHostToDevice));
+                if (d.recvCount[pr]) HIP_TRY(hipMemcpy(ri, I.part.recv[pr].data(), (size_t)d.recvCount[pr] * 4, hipMemcpyHostToDevice));
+                d.sendIdx[pr] = si; d.recvIdx[pr] = ri;
+            }
+            I.windowBytes = sizeof(DistWindow) + off * sizeof(double);
+            void* w = nullptr;
+            HIP_TRY(hipExtMallocWithFlags(&w, I.windowBytes, hipDeviceMallocFinegrained));
+            HIP_TRY(hipMemset(w, 0, I.windowBytes));
+            I.window = static_cast<DistWindow*>(w);
+            d.win[rank_] = I.window;
+            d.payload[rank_] = reinterpret_cast<double*>(reinterpret_cast<char*>(w) + sizeof(DistWindow));
+            HIP_TRY(dev_alloc(I.allocs, I.devDist, 1));
+            I.pushBlocks = (maxSend + SF3D_BLOCK - 1) / SF3D_BLOCK;
+            if (I.pushBlocks == 0) I.pushBlocks = 1;
+            if (I.pushBlocks > 256) I.pushBlocks = 256;
+        }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
         HIP_TRY(dev_alloc(I.allocs, v.part0, v.nb)); HIP_TRY(dev_alloc(I.allocs, v.part1, v.nb));
@@ -1098,10 +1345,64 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
     return SF3D_OK;
 }
 
+sf3d_error_t DeviceSolver::dist_prepare(int rank, int world)
+{
+    if (world < 1 || world > SF3D_MAX_RANKS || rank < 0 || rank >= world) { snprintf(err_, sizeof(err_), "dist_prepare: bad rank/world %d/%d", rank, world); return SF3D_PARAMETER_ERROR; }
+    if (built_) { snprintf(err_, sizeof(err_), "dist_prepare must precede the first device build (call it before sf3d_initialize)"); return SF3D_SOLVER_ERROR; }
+    world_ = world; rank_ = rank; connected_ = false;
+    return SF3D_OK;
+}
+
+/* builds the device state (so the window exists) and returns what the peers need to reach it */
+sf3d_error_t DeviceSolver::dist_export(HostModel& m, const ParamsHost& p, DistBlob* out)
+{
+    sf3d_error_t e = sync_to_device(m, p);
+    if (e != SF3D_OK) return e;
+    std::memset(out, 0, sizeof(*out));
+    out->world = world_; out->rank = rank_; out->nodes = m.N;
+    if (world_ == 1) return SF3D_OK;
+    Impl& I = *impl_;
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, I.window));
+    static_assert(sizeof(h) <= sizeof(out->ipcHandle), "ipc handle size");
+    std::memcpy(out->ipcHandle, &h, sizeof(h));
+    for (int r = 0; r < world_; ++r) { out->recvOff[r] = I.hostDist.recvOff[r]; out->recvCount[r] = I.hostDist.recvCount[r]; }
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
+{
+    if (world_ == 1) { connected_ = true; return SF3D_OK; }
+    if (!built_) { snprintf(err_, sizeof(err_), "dist_connect before dist_export"); return SF3D_SOLVER_ERROR; }
+    Impl& I = *impl_;
+    HIP_TRY(hipSetDevice(I.device));
+    DistView& d = I.hostDist;
+    for (int r = 0; r < world_; ++r) {
+        const DistBlob& b = all[r];
+        if ((int)b.world != world_ || (int)b.rank != r || b.nodes != I.N) { snprintf(err_, sizeof(err_), "dist_connect: blob %d does not match (world %u rank %u nodes %llu)", r, b.world, b.rank, (unsigned long long)b.nodes); return SF3D_PARAMETER_ERROR; }
+        if (r == rank_) continue;
+        /* both sides derived the lists from the same global graph: counts must agree */
+        if (b.recvCount[rank_] != d.sendCount[r]) { snprintf(err_, sizeof(err_), "dist_connect: rank %d expects %u nodes from me, I send %u", r, b.recvCount[rank_], d.sendCount[r]); return SF3D_TOPOGRAPHY_ERROR; }
+        d.sendOff[r] = b.recvOff[rank_];
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, b.ipcHandle, sizeof(h));
+        void* ptr = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        I.peerMaps.push_back(ptr);
+        d.win[r] = static_cast<DistWindow*>(ptr);
+        d.payload[r] = reinterpret_cast<double*>(static_cast<char*>(ptr) + sizeof(DistWindow));
+    }
+    HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
+    I.v.dist = I.devDist;
+    connected_ = true;
+    return SF3D_OK;
+}
+
 sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p, double* out)
 {
     sf3d_error_t e = sync_to_device(m, p);
     if (e != SF3D_OK) return e;
+    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect"); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     hipLaunchKernelGGL(k_storage, dim3(I.v.nb), dim3(SF3D_BLOCK), 0, I.stream, I.v);
     hipLaunchKernelGGL(k_decide_query, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v);
@@ -1135,9 +1436,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
 {
     sf3d_error_t e = sync_to_device(m, p);
     if (e != SF3D_OK) return e;
+    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect"); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     const DevView& v = I.v;
     const dim3 grid(v.nb), block(SF3D_BLOCK), one(1);
+    const bool multi = world_ > 1;
+    const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
     auto timed = [&](int kid, auto launch) {
@@ -1158,6 +1462,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (stage == ST_ATTEMPT || stage == ST_APPROX) {
             hipLaunchKernelGGL(k_attempt_begin, one, one, 0, st, v.ctrl);
             timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props, grid, block, 0, st, v); });
+            if (multi) {
+                hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
+                hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
+            }
             timed(KID_ASSEMBLE, [&] {
                 hipLaunchKernelGGL(k_assemble_surface, dim3(v.nbSurf), block, 0, st, v);
                 if (v.nbSoil) hipLaunchKernelGGL(k_assemble_soil, dim3(v.nbSoil), block, 0, st, v);
@@ -1169,6 +1477,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (chunk > 40) chunk = 40;
         for (uint32_t k = 0; k < chunk; ++k) {
             timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep, grid, block, 0, st, v); });
+            if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }
         timed(KID_POST, [&] { hipLaunchKernelGGL(k_post, grid, block, 0, st, v); });
@@ -1210,6 +1519,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (++guard > 1000000) { snprintf(err_, sizeof(err_), "step state machine did not terminate (stage %u)", stage); return SF3D_SOLVER_ERROR; }
     }
     mirror_ = *I.hostCtrl;
+    if (mirror_.distError) snprintf(err_, sizeof(err_), "rank %d: a peer did not answer within the bounded wait (multi-GPU exchange)", rank_);
     p.dtCurr = mirror_.dtCurr;
     *dtOut = mirror_.dt;
     m.hostStaleState = true;

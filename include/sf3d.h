@@ -327,6 +327,24 @@ const char*  sf3d_kernel_name(int k);
  * enabled (drains the event pool) */
 sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint64_t* nodes_per_launch);
 
+/* ---- multi-GPU: one process per GPU, row strips of surface-cell columns ------
+ * Every rank builds the SAME global model through the setters above; the library computes only the
+ * strip it owns and exchanges one-cell halos with its neighbours device-to-device (HIP-IPC windows
+ * over xGMI, device-side flags).  Call order: sf3d_dist_prepare(rank, world) -> sf3d_initialize ...
+ * graph / state setters ... -> sf3d_dist_export(blob) -> [the launcher all-gathers the blobs, e.g.
+ * torch.distributed / MPI] -> sf3d_dist_connect(all blobs) -> sf3d_initialize_balance -> steps.
+ * Getters answer for the nodes a rank owns (sf3d_dist_owner); scalar balances are global. */
+int          sf3d_dist_blob_bytes(void);
+sf3d_error_t sf3d_dist_prepare(int rank, int world);
+sf3d_error_t sf3d_dist_export(void* blob_out);
+sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
+/* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
+sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* owner_out);
+/* halo lists of `rank` in a world of `world`: direction 0 = nodes sent to `peer`, 1 = nodes received
+ * from `peer` (sorted global indices; pass out = NULL to query the count) */
+sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32_t capacity,
+                            uint32_t* out, uint32_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -160,4 +160,12 @@ int sf3d_kernel_count(void) { return 0; }
 const char* sf3d_kernel_name(int) { return nullptr; }
 sf3d_error_t sf3d_kernel_stats(int, uint64_t*, double*, uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 
+/* multi-GPU entry points exist only in the HIP product */
+int sf3d_dist_blob_bytes(void) { return 0; }
+sf3d_error_t sf3d_dist_prepare(int, int) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_dist_export(void*) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_dist_connect(const void*) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_dist_owner(int, uint32_t, uint32_t, int32_t*) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_dist_halo(int, int, int, int, uint32_t, uint32_t*, uint32_t*) { return SF3D_MISSING_DATA_ERROR; }
+
 } /* extern "C" */

@@ -1,0 +1,51 @@
+"""One rank of a multi-rank run of the HIP product (one process per rank; all ranks may share one
+GPU for functional tests).  The control plane is torch.distributed with the gloo backend.
+usage: python scripts/multirank_worker.py <rank> <world> <port> <case> <outfile>"""
+import os, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+import torch.distributed as dist
+from criteria3d_amd import capi, catchment as cm
+
+rank, world, port, case, outfile = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(port)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+
+def allgather(b):
+    out = [None] * world
+    dist.all_gather_object(out, b)
+    return out
+
+sf = capi.load_product()
+sf.check(sf.lib.sf3d_set_device(int(os.environ.get("SF3D_TEST_DEVICE", "0"))), "set_device")
+if case == "c2f20":
+    m, plan = cm.catchment_model(64, 64, 10), [20.0, 0.0]
+elif case == "c2f60":
+    m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
+elif case == "het":
+    m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
+elif case == "ragged":
+    m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
+else:
+    raise SystemExit("unknown case")
+sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+cm.build(sf, m, threads=1, dist=(rank, world, allgather))
+owner = sf.owner_map(world, m.n)
+res = {"owner": owner}
+t0 = time.time()
+for h, item in enumerate(plan):
+    mm, mx = item if isinstance(item, tuple) else (item, None)
+    steps, dts = cm.run_hour(sf, m, mm, max_steps=mx)
+    s = cm.snapshot(sf, m)
+    res[f"dts_h{h}"] = np.array(dts)
+    res[f"H_h{h}"] = s["H"]; res[f"Se_h{h}"] = s["Se"]
+    for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
+        res[f"{k}_h{h}"] = np.array(s[k])
+res["seconds"] = np.array(time.time() - t0)
+c = sf.counters()
+res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
+np.savez(outfile, **res)
+dist.barrier()
+sf.lib.sf3d_clean()
+dist.destroy_process_group()

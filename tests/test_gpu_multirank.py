@@ -1,0 +1,77 @@
+"""Multi-rank path of the HIP product on real hardware: N processes (one per rank) share the GPU of
+the test box - the exchange (HIP-IPC windows, device-side flags, halo puts, all-gather of partial
+sums) is the same code that runs one rank per GPU.  Each rank owns a row strip; the union of the
+owned nodes must match the oracle like the single-rank run does."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from criteria3d_amd import capi, catchment as cm
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+RTOL = 1e-6
+
+
+def run_ranks(world, case, tmp_path, port):
+    procs, outs = [], []
+    for r in range(world):
+        out = tmp_path / f"rank{r}.npz"
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), str(world),
+                                       str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [np.load(o) for o in outs]
+
+
+def oracle_reference(oracle, case):
+    if case == "c2f20":
+        m, plan = cm.catchment_model(64, 64, 10), [20.0, 0.0]
+    elif case == "c2f60":
+        m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
+    elif case == "het":
+        m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
+    else:
+        m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
+    oracle.lib.sf3d_reset_solver_state()
+    cm.build(oracle, m, threads=1)
+    out = []
+    for item in plan:
+        mm, mx = item if isinstance(item, tuple) else (item, None)
+        _, dts = cm.run_hour(oracle, m, mm, max_steps=mx)
+        out.append((dts, cm.snapshot(oracle, m)))
+    return m, out
+
+
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614)])
+def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
+    ranks = run_ranks(world, case, tmp_path, port)
+    m, ref = oracle_reference(oracle, case)
+    owner = ranks[0]["owner"]
+    assert set(np.unique(owner)) == set(range(world))
+    for h, (dts, snap) in enumerate(ref):
+        H = np.empty(m.n); Se = np.empty(m.n)
+        for r, res in enumerate(ranks):
+            mine = owner == r
+            H[mine] = res[f"H_h{h}"][mine]; Se[mine] = res[f"Se_h{h}"][mine]
+            np.testing.assert_allclose(res[f"dts_h{h}"], dts, rtol=1e-12)            # identical decisions on every rank
+            assert abs(float(res[f"storage_h{h}"]) - snap["storage"]) <= RTOL * abs(snap["storage"])
+        assert np.max(np.abs(H - snap["H"]) / np.maximum(np.abs(snap["H"]), 1e-9)) < RTOL
+        assert np.max(np.abs(Se - snap["Se"])) < 1e-6
+        # boundary sums are reported per rank for its own nodes: they add up to the global ones
+        for k in ("runoff", "drainage", "lateral"):
+            tot = sum(float(res[f"{k}_h{h}"]) for res in ranks)
+            assert abs(tot - snap[k]) <= RTOL * max(abs(snap[k]), 1e-3), (k, tot, snap[k])
+    assert all((res["counters"] == ranks[0]["counters"]).all() for res in ranks)
