@@ -131,16 +131,32 @@ def main():
     if not torch.cuda.is_available():
         log("[bench] no GPU visible: the product path has no CPU fallback")
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; SF3D_BENCH_SHARE_GPU=1 (functional testing on a 1-GPU box) puts every rank on
+    # device 0 and uses gloo for the control plane, because RCCL refuses two ranks on one device
+    share = os.environ.get("SF3D_BENCH_SHARE_GPU") == "1"
+    device = 0 if share else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def allgather_bytes(b):
+        out = [None] * world
+        dist.all_gather_object(out, b)
+        return out
 
     if rank == 0 and not os.environ.get("SF3D_PRODUCT_LIB"):
         build.build_product()
-    if world > 1:
-        dist.barrier()
+    barrier()
     sf = capi.load_product()
-    sf.check(sf.lib.sf3d_set_device(local_rank), "set_device")
+    sf.check(sf.lib.sf3d_set_device(device), "set_device")
+    shard = (rank, world, allgather_bytes) if world > 1 else None
 
     nx, ny, nz = WORKLOADS[args.workload]
     t0 = time.perf_counter()
@@ -149,7 +165,7 @@ def main():
 
     def fresh():
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, model, threads=1)
+        cm.build(sf, model, threads=1, dist=shard)
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
 
     t0 = time.perf_counter()
@@ -161,15 +177,14 @@ def main():
 
     sf.check(sf.lib.sf3d_kernel_timing(1), "kernel_timing")
     per_step, hour_starts = [], []
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     c0 = sf.counters()
     elapsed = run_hours(sf, cm, model, args.forcing, args.steps, per_step=per_step, hour_starts=hour_starts)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     c1 = sf.counters()
@@ -177,7 +192,9 @@ def main():
     sf.lib.sf3d_kernel_timing(0)
 
     if rank != 0:
+        sf.lib.sf3d_clean()
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -187,13 +204,14 @@ def main():
     roofline = None
     if dom and stats[dom][0] > 0:
         launches, ms, nodes = stats[dom]
+        nodes = nodes // world                    # each rank sweeps its own strip
         avg_s = ms / 1e3 / launches
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
                     "kernels": {k: {"launches": v[0], "total_ms": v[1],
-                                    "GBps": (ALGO_BYTES[k] * v[2] * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
+                                    "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
                                 for k, v in stats.items()}}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -218,13 +236,15 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} tilted-plane catchment (SURVEY.md 8d), forcing {args.forcing}, "
                                f"{args.steps} simulated hours from the initial state",
-                   "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips",
+                   "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
     print(json.dumps(line), flush=True)
+    sf.lib.sf3d_clean()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

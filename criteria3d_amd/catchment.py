@@ -168,7 +168,7 @@ def catchment_model(nx: int, ny: int, nz: int, heterogeneous: bool = False, cell
                  cell_area=area, shape=(nx, ny, nz), meta=dict(kind="catchment", heterogeneous=heterogeneous))
 
 
-def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None):
+def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool = True):
     """Push a Model through the ABI in the caller's order.
 
     dist = (rank, world, allgather) shards the model over `world` ranks (HIP product only):
@@ -196,6 +196,8 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None):
     psi = np.full(m.n, m.psi0_soil)
     psi[:m.ns] = m.psi0_surface
     sf.set_matric_potential_bulk(0, psi)
+    if not finalize:          # host-side staging only (partition queries on a machine without a GPU)
+        return
     if dist is not None:
         sf.dist_connect(dist[0], dist[1], dist[2])
     sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")

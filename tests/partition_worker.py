@@ -1,0 +1,104 @@
+"""One gloo rank of the CPU test of the N>1 path: the product library's host-side partition plan
+(row strips + halo lists, no GPU involved) drives a partitioned Jacobi iteration in numpy whose halo
+exchange and partial-sum all-gather follow exactly the plan and protocol the device code uses
+(owner computes its rows; after every sweep each rank sends the values on its send lists and
+receives its recv lists; partial norms are combined in rank order).  Exit code 0 = the sharded
+iteration reproduces the global one."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from criteria3d_amd import capi, catchment as cm  # noqa: E402
+
+
+def jacobi_rows(rows, A, J, b, x):
+    """x_new[i] = b[i] - sum_s A[s, i] * x[J[s, i]] for i in rows (slot order as the solver)."""
+    xn = b[rows].copy()
+    for s in (0, 2, 3, 4, 5, 6, 7, 8, 9, 1):
+        xn -= A[s, rows] * x[J[s, rows]]
+    return xn
+
+
+def main():
+    rank, world, port, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = cm.catchment_model(24, 40, 5) if case == "grid" else cm.ragged_model(9, 30, 4)
+    sf = capi.load_product()
+    cm.build(sf, m, finalize=False)                       # host staging only: no device call
+    owner = sf.owner_map(world, m.n)
+    send = [sf.halo_list(rank, world, p, 0) for p in range(world)]
+    recv = [sf.halo_list(rank, world, p, 1) for p in range(world)]
+    sf.lib.sf3d_clean()
+
+    # the same random, diagonally dominant system on every rank (static ELL over the model's links)
+    rng = np.random.RandomState(123)
+    J = np.tile(np.arange(m.n), (10, 1))
+    A = np.zeros((10, m.n))
+    nlat = np.zeros(m.n, np.int64)
+    for node, to, d in zip(m.link_node, m.link_to, m.link_dir):
+        if d == capi.LINK_UP: s = 0
+        elif d == capi.LINK_DOWN: s = 1
+        else:
+            s = 2 + nlat[node]; nlat[node] += 1
+        J[s, node] = to
+        A[s, node] = -rng.uniform(0.01, 0.09)
+    b = rng.uniform(-1, 1, m.n)
+    x0 = rng.uniform(-1, 1, m.n)
+
+    # plan checks: strips cover every node once; my recv from p == p's send to me
+    assert set(np.unique(owner)) == set(range(world))
+    lists = [None] * world
+    dist.all_gather_object(lists, {"send": [l.tolist() for l in send], "recv": [l.tolist() for l in recv]})
+    for p in range(world):
+        assert lists[p]["send"][rank] == recv[p].tolist(), "recv list != peer's send list"
+        assert (owner[recv[p]] == p).all() and (owner[send[p]] == rank).all()
+    mine = np.flatnonzero(owner == rank)
+    needed = np.unique(J[:, mine][A[:, mine] != 0])
+    halo = np.concatenate([r for r in recv]) if world > 1 else np.array([], np.int64)
+    assert set(needed[owner[needed] != rank]) <= set(halo.tolist()), "a neighbour value is missing from the halo lists"
+
+    # global iteration (reference) and sharded iteration
+    xg = x0.copy()
+    xs = x0.copy()
+    xs[owner != rank] = np.nan                            # a rank never holds other strips' values ...
+    for p in range(world):
+        xs[recv[p]] = x0[recv[p]]                         # ... except its one-cell halo
+    for it in range(12):
+        new = jacobi_rows(np.arange(m.n), A, J, b, xg)
+        gnorm_parts = [np.abs(new[owner == r] - xg[owner == r]).sum() for r in range(world)]
+        xg = new
+        mynew = jacobi_rows(mine, A, J, b, xs)
+        part = np.abs(mynew - xs[mine]).sum()
+        xs[mine] = mynew
+        # halo exchange following the plan (device: puts into the peer's window)
+        reqs, bufs = [], {}
+        for p in range(world):
+            if p == rank: continue
+            if len(send[p]):
+                reqs.append(dist.isend(torch.from_numpy(xs[send[p]].copy()), p))
+            if len(recv[p]):
+                bufs[p] = torch.empty(len(recv[p]), dtype=torch.float64)
+                reqs.append(dist.irecv(bufs[p], p))
+        for r in reqs: r.wait()
+        for p, t in bufs.items(): xs[recv[p]] = t.numpy()
+        # all-gather of partial sums, combined in rank order (device: mailboxes in the windows)
+        parts = [None] * world
+        dist.all_gather_object(parts, float(part))
+        total, gtotal = 0.0, 0.0
+        for r in range(world):
+            total += parts[r]; gtotal += gnorm_parts[r]
+        assert total == gtotal, (it, total, gtotal)
+        assert np.array_equal(xs[mine], xg[mine]), f"sweep {it}: owned rows differ from the global iteration"
+        assert np.array_equal(xs[halo], xg[halo]) if len(halo) else True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
