@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -175,7 +176,8 @@ def main():
         run_hours(sf, cm, model, args.forcing, args.warmup)
         fresh()
 
-    sf.check(sf.lib.sf3d_kernel_timing(1), "kernel_timing")
+    # HIP events around the dominant kernel only (mode 2); --time-all-kernels instruments every node kernel
+    sf.check(sf.lib.sf3d_kernel_timing(1 if args.time_all_kernels else 2), "kernel_timing")
     per_step, hour_starts = [], []
     barrier()
     torch.cuda.synchronize()
@@ -200,15 +202,25 @@ def main():
 
     work = {k: c1[k] - c0[k] for k in c1}
     # dominant kernel by measured device time
-    dom = max(stats, key=lambda k: stats[k][1]) if stats else None
+    dom = max(stats, key=lambda k: stats[k][1]) if stats else None      # k_sweep unless --time-all-kernels finds another
     roofline = None
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs
+    # of this same command, corrected per MI355X_MICROARCH.md: 2 x FETCH_SIZE + WRITE_SIZE); bench.py
+    # cannot collect counters itself
+    traffic = None
+    try:
+        prof = json.load(open(ROOT / "profiles" / "r01_b_kernel_summary.json"))
+        if world == 1 and args.workload == "C4" and dom in prof and "hbm_traffic_MB" in prof[dom]:
+            traffic = prof[dom]["hbm_traffic_MB"] * 1e6
+    except Exception:  # noqa: BLE001
+        pass
     if dom and stats[dom][0] > 0:
         launches, ms, nodes = stats[dom]
         nodes = nodes // world                    # each rank sweeps its own strip
         avg_s = ms / 1e3 / launches
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
                     "kernels": {k: {"launches": v[0], "total_ms": v[1],
                                     "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}

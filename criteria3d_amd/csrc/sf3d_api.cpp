@@ -598,7 +598,7 @@ sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32
     return SF3D_OK;
 }
 
-sf3d_error_t sf3d_kernel_timing(int enable) { return dev().timing(enable != 0); }
+sf3d_error_t sf3d_kernel_timing(int mode) { return dev().timing(mode); }
 int sf3d_kernel_count(void) { return KID_COUNT; }
 const char* sf3d_kernel_name(int k) { return DeviceSolver::kernel_name(k); }
 sf3d_error_t sf3d_kernel_stats(int k, uint64_t* n, double* ms, uint64_t* nodes) { return dev().stats(k, n, ms, nodes); }

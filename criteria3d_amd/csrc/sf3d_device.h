@@ -4,7 +4,7 @@
  *
  * Data layout in HBM (all fp64 unless noted, node arrays in caller order: layer-major,
  * surface nodes first - the ordering the reference relies on):
- *   static graph   lto[10][N] u32, lkind[10][N] u8, larea[10][N], ldist[10][N]  (slot-major:
+ *   static graph   lto[10][N] u32, lkind[10][N] u8, lgeo[10][N] {area, dist}  (slot-major:
  *                  slot 0 Up, 1 Down, 2..9 laterals; consecutive threads read consecutive
  *                  nodes of one slot => coalesced), z, size, pond, cls u16, btype u8,
  *                  bslope, bsize, prescribed; per (64-node chunk, slot) descriptors ckind/cdelta
@@ -13,7 +13,8 @@
  *   state          X[4][N]: pool of head buffers; H, Hold and Hbest are INDICES into the
  *                  pool kept in Ctrl (no copies on step begin / reject / keep-best / restore)
  *                  Se, K, C, flow, sink, bflowRate, bflowSum, lflowSum[10][N]
- *   linear system  A[10][N] row-normalised off-diagonals (static ELL, zeros kept), b
+ *   linear system  A2[5][N] row-normalised off-diagonals (static ELL, zeros kept; slots paired so
+ *                  every access is 16 B per lane), b
  *   control block  Ctrl: solver parameters, adaptive dt, stage of the step state machine,
  *                  balances, counters - decisions are taken on the device by 1-block kernels
  */
@@ -45,6 +46,9 @@ enum : uint32_t {
     ST_DONE = 7,        /* step accepted                                                     */
     ST_FAIL = 8         /* stepNan                                                           */
 };
+
+/* 16-byte pair; plain struct so host code can use it too */
+struct alignas(16) sf3d_d2 { double x, y; };
 
 struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
@@ -131,9 +135,9 @@ struct DevView {
     const double *bslope, *bsize, *prescribed;
     const uint32_t* lto;                /* [10][N] */
     const uint8_t* lkind;               /* [10][N] */
-    const double *larea, *ldist;        /* [10][N] */
+    const sf3d_d2* lgeo;                /* [10][N] {interface area, link distance}: one 16-byte load per link */
     double* lflowSum;                   /* [10][N] */
-    double* A;                          /* [10][N] */
+    sf3d_d2* A2;                        /* [5][N] row-normalised off-diagonals, slots paired (2p, 2p+1): 16-byte accesses */
     double *b, *C;
     double* X[SF3D_POOL];
     double *Se, *SeHold, *K, *flow, *bflowRate, *bflowSum;   /* SeHold = Se(Hold), written at approximation 0 */

@@ -107,7 +107,7 @@ public:
     int world() const { return world_; }
     int rank() const { return rank_; }
     /* instrumentation */
-    sf3d_error_t timing(bool enable);
+    sf3d_error_t timing(int mode);               /* 0 off, 1 all node kernels, 2 only the Jacobi sweep */
     sf3d_error_t stats(int kid, uint64_t* launches, double* ms, uint64_t* nodes);
     static const char* kernel_name(int kid);
 

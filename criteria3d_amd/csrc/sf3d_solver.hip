@@ -119,7 +119,9 @@ __device__ __forceinline__ double mualem_k(const SoilDev& s, double Se, uint32_t
         const double tNum = 1.0 - pow(1.0 - seScPow, s.m);
         temp = tNum / s.mualemDen;
     } else return NODATA_D;
-    return s.Ksat * pow(Se, s.L) * (temp * temp);
+    /* Mualem tortuosity Se^L: L = 0.5 in every soil table of the application -> correctly rounded sqrt */
+    const double seL = (s.L == 0.5) ? sqrt(Se) : pow(Se, s.L);
+    return s.Ksat * seL * (temp * temp);
 }
 __device__ __forceinline__ double dtheta_dh(const SoilDev& s, double H, double Ho, double z, uint32_t wrc)   /* :224-279 */
 {
@@ -168,7 +170,7 @@ __device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c,
                 rate = -dmin(val, maxFlow);
                 break; }
             case SF3D_BND_FREE_DRAINAGE:                              /* :680-684, Up-link area */
-                rate = -K * v.larea[i];
+                rate = -K * v.lgeo[i].x;
                 break;
             case SF3D_BND_FREE_LATERAL_DRAINAGE:                      /* :686-690 */
                 rate = -K * v.bsize[i] * v.bslope[i] * c->lvRatio;
@@ -562,7 +564,8 @@ __device__ __forceinline__ double infiltration_conductance(const DevView& v, con
                                                            const double* __restrict__ Xc, const double* __restrict__ Xh,
                                                            double Hi, double Hoi, double zi)
 {
-    const double area = v.larea[e], dist = v.ldist[e];
+    const sf3d_d2 geo = v.lgeo[e];
+    const double area = geo.x, dist = geo.y;
     const double dt = c->dt;
     const bool iSurf = i < v.ns;
     const uint32_t su = iSurf ? i : j, so = iSurf ? j : i;
@@ -598,7 +601,8 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
                                                    const double* __restrict__ Xh, double Hi, double Hoi,
                                                    double zi, double& courant)
 {
-    const double area = v.larea[e], dist = v.ldist[e];
+    const sf3d_d2 geo = v.lgeo[e];
+    const double area = geo.x, dist = geo.y;
     const double dt = c->dt;
     if (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT) {
         double ki = v.K[i], kj = v.K[j];
@@ -641,8 +645,11 @@ __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd,
     const double cdt = Ci / dt;
     const double inv = 1.0 / (cdt + sum);
     #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s)
-        if (cd.kind[s] != CK_NONE) v.A[(size_t)s * v.N + i] = (k[s] * -1.) * inv;
+    for (int p = 0; p < SF3D_SLOTS / 2; ++p)
+        if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) {
+            sf3d_d2 a; a.x = (k[2 * p] * -1.) * inv; a.y = (k[2 * p + 1] * -1.) * inv;
+            v.A2[(size_t)p * v.N + i] = a;
+        }
     v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
 }
 
@@ -718,7 +725,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(De
                     const size_t e = (size_t)s * v.N + i;
                     if (cd.kind[s] == CK_MIXED) { kd[t] = v.lkind[e]; j[t] = v.lto[e]; }
                     else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
-                    area[t] = v.larea[e]; dist[t] = v.ldist[e];
+                    const sf3d_d2 geo = v.lgeo[e]; area[t] = geo.x; dist[t] = geo.y;
                 }
             }
             #pragma unroll
@@ -752,7 +759,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     if (c->stage != ST_SWEEP) return;
     const double* __restrict__ xin = v.X[c->cur];
     double* __restrict__ xout = v.X[free_buffer(c)];
-    const double* __restrict__ A = v.A;
+    const sf3d_d2* __restrict__ A2 = v.A2;
     double nrm = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
@@ -760,7 +767,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
         double a[SF3D_SLOTS], xj[SF3D_SLOTS];
         uint32_t j[SF3D_SLOTS];
         #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) a[s] = A[(size_t)s * v.N + i];
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
         const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
         #pragma unroll
         for (int s = 0; s < SF3D_SLOTS; ++s) {
@@ -854,7 +861,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_ACCEPT) return;
     const double* __restrict__ X = v.X[c->cur];
-    const double* __restrict__ A = v.A;
+    const sf3d_d2* __restrict__ A2 = v.A2;
     const double dt = c->dt;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
@@ -862,7 +869,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
         double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
         uint32_t j[SF3D_SLOTS];
         #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) a[s] = A[(size_t)s * v.N + i];      /* non-zero only where a link exists */
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }   /* non-zero only where a link exists */
         const ChunkDesc cd = v.cdesc[q];
         #pragma unroll
         for (int s = 0; s < SF3D_SLOTS; ++s) {
@@ -996,7 +1003,7 @@ struct DeviceSolver::Impl {
     DistView* devDist = nullptr;
     uint32_t pushBlocks = 0;
     /* timing */
-    bool timing = false;
+    int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep */
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
     std::vector<hipEvent_t> freeEvents;
@@ -1106,7 +1113,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         /* derived static graph data: link kind and link distance (host, libm - exactly the
          * reference's nodeDistance2D/3D arithmetic, soilPhysics.cpp:328-338) */
         std::vector<uint8_t> kind(NS, LK_NONE);
-        std::vector<double> dist(NS, 0.), area(NS, 0.);
+        std::vector<sf3d_d2> geo(NS, sf3d_d2{0., 0.});
         std::vector<uint32_t> to(NS, 0u);
         bool bad = false;
         parallel_for(N, [&](uint32_t a, uint32_t b) {
@@ -1117,24 +1124,24 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (m.ltype[s][i] == SF3D_LINK_NONE) continue;
                     const uint32_t j = m.lto[s][i];
                     const size_t e = (size_t)s * N + i;
-                    to[e] = j; area[e] = m.larea[s][i];
+                    to[e] = j; geo[e].x = m.larea[s][i];
                     const bool si = i >= ns, sj = j >= ns;
                     if (si && sj) {
                         if (m.ltype[s][i] == SF3D_LINK_LATERAL) {
                             kind[e] = LK_SOIL_LAT;
                             const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j], dz = m.z[i] - m.z[j];
                             double nrm = 0; nrm += dx * dx; nrm += dy * dy; nrm += dz * dz;
-                            dist[e] = std::sqrt(nrm);
-                        } else { kind[e] = LK_SOIL_VERT; dist[e] = std::fabs(m.z[i] - m.z[j]); }
+                            geo[e].y = std::sqrt(nrm);
+                        } else { kind[e] = LK_SOIL_VERT; geo[e].y = std::fabs(m.z[i] - m.z[j]); }
                     } else if (!si && !sj) {
                         kind[e] = LK_RUNOFF;
                         const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j];
                         double nrm = 0; nrm += dx * dx; nrm += dy * dy;
-                        dist[e] = std::sqrt(nrm);
+                        geo[e].y = std::sqrt(nrm);
                     } else {
                         kind[e] = LK_INFILTRATION;
                         const uint32_t su = sj ? i : j, so = sj ? j : i;
-                        dist[e] = m.z[su] - m.z[so];
+                        geo[e].y = m.z[su] - m.z[so];
                     }
                 }
                 if (m.btype[i] == SF3D_BND_FREE_DRAINAGE && m.ltype[0][i] == SF3D_LINK_NONE) bad = true;   /* assert water.cpp:682 */
@@ -1197,7 +1204,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
 
-        double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *larea, *ldist, *roughness;
+        double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness; sf3d_d2* lgeo;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
         HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
         HIP_TRY(dev_alloc(I.allocs, pond, N)); HIP_TRY(dev_alloc(I.allocs, sink, N));
@@ -1205,8 +1212,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, bslope, N)); HIP_TRY(dev_alloc(I.allocs, bsize, N));
         HIP_TRY(dev_alloc(I.allocs, prescribed, N));
         HIP_TRY(dev_alloc(I.allocs, lto, NS)); HIP_TRY(dev_alloc(I.allocs, lkind, NS));
-        HIP_TRY(dev_alloc(I.allocs, larea, NS)); HIP_TRY(dev_alloc(I.allocs, ldist, NS));
-        HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A, NS));
+        HIP_TRY(dev_alloc(I.allocs, lgeo, NS));
+        HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A2, NS / 2));
         HIP_TRY(dev_alloc(I.allocs, v.b, N)); HIP_TRY(dev_alloc(I.allocs, v.C, N));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
         HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N)); HIP_TRY(dev_alloc(I.allocs, v.SeHold, N));
@@ -1256,7 +1263,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
         v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
         v.bslope = bslope; v.bsize = bsize; v.prescribed = prescribed;
-        v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
+        v.lto = lto; v.lkind = lkind; v.lgeo = lgeo; v.soils = soils; v.roughness = roughness;
         v.cdesc = dcdesc;
 
         std::vector<SoilDev> sd(m.soils.size());
@@ -1269,12 +1276,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpy(cls, m.cls.data(), N * 2, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lto, to.data(), NS * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lkind, kind.data(), NS, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(larea, area.data(), NS * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ldist, dist.data(), NS * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lgeo, geo.data(), NS * sizeof(sf3d_d2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dcdesc, cdesc.data(), cdesc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
         if (!sd.empty()) HIP_TRY(hipMemcpy(soils, sd.data(), sd.size() * sizeof(SoilDev), hipMemcpyHostToDevice));
         if (!m.roughness.empty()) HIP_TRY(hipMemcpy(roughness, m.roughness.data(), m.roughness.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset(v.A, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
+        HIP_TRY(hipMemset(v.A2, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
         HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8)); HIP_TRY(hipMemset(v.SeHold, 0, N * 8));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(hipMemset(v.X[k], 0, N * 8));
         HIP_TRY(hipDeviceSynchronize());      /* null-stream fills must land before the (non-blocking) solver stream runs */
@@ -1414,7 +1420,7 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
     return SF3D_OK;
 }
 
-sf3d_error_t DeviceSolver::timing(bool enable)
+sf3d_error_t DeviceSolver::timing(int enable)
 {
     if (!impl_) impl_ = new Impl();
     impl_->timing = enable;
@@ -1445,7 +1451,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     hipStream_t st = I.stream;
 
     auto timed = [&](int kid, auto launch) {
-        if (!I.timing) { launch(); return; }
+        if (!I.timing || (I.timing == 2 && kid != KID_SWEEP)) { launch(); return; }
         hipEvent_t a, b;
         if (I.freeEvents.size() >= 2) { a = I.freeEvents.back(); I.freeEvents.pop_back(); b = I.freeEvents.back(); I.freeEvents.pop_back(); }
         else { hipEventCreate(&a); hipEventCreate(&b); }

@@ -317,9 +317,10 @@ sf3d_error_t sf3d_set_device(int device);
 /* Upload every pending host-side edit (sinks, ponds, state, parameters) to the device and block
  * until all queued device work of the solver stream has finished. */
 sf3d_error_t sf3d_synchronize(void);
-/* Per-kernel HIP-event timing on the solver's own stream.  enable=1 starts recording an event
- * pair around every launch of the kernels listed by sf3d_kernel_name(); enable=0 stops. */
-sf3d_error_t sf3d_kernel_timing(int enable);
+/* Per-kernel HIP-event timing on the solver's own stream.  mode 1 records an event pair around
+ * every launch of the kernels listed by sf3d_kernel_name(), mode 2 only around the Jacobi sweep
+ * (the dominant kernel; cheaper), mode 0 stops.  Guarded launches that did no work are not counted. */
+sf3d_error_t sf3d_kernel_timing(int mode);
 /* number of instrumented kernels; name of kernel k (NULL if out of range) */
 int          sf3d_kernel_count(void);
 const char*  sf3d_kernel_name(int k);

@@ -1,0 +1,37 @@
+"""Summarise a scripts/profile_gpu.sh run: per-kernel average duration of the launches that did work
+(kernel trace) and HBM traffic per launch from the PMC passes, corrected as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B
+request: x2; WRITE_SIZE exact; both in KiB)."""
+import csv, glob, json, sys, collections
+out = sys.argv[1]
+res = {}
+f = glob.glob(f"{out}/trace/*/*kernel_trace.csv")
+if f:
+    dur = collections.defaultdict(list)
+    for row in csv.DictReader(open(f[0])):
+        dur[row["Kernel_Name"].split("(")[0]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, v in dur.items():
+        active = [x for x in v if x > 0.25 * max(v)] if k in ("k_sweep", "k_props", "k_assemble_soil", "k_assemble_surface", "k_post", "k_accept", "k_restore") else v
+        res.setdefault(k, {})["launches"] = len(v)
+        res[k]["active_launches"] = len(active)
+        res[k]["avg_active_us"] = sum(active) / max(len(active), 1) / 1e3
+        res[k]["total_ms"] = sum(v) / 1e6
+for cnt, key, corr in (("FETCH_SIZE", "hbm_read_MB", 2.0), ("WRITE_SIZE", "hbm_write_MB", 1.0)):
+    f = glob.glob(f"{out}/pmc_{cnt}/*/*counter_collection.csv")
+    if not f: continue
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f[0])):
+        agg[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+    for k, v in agg.items():
+        big = [x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v
+        res.setdefault(k, {})[key] = corr * (sum(big) / max(len(big), 1)) * 1024 / 1e6
+for k, v in res.items():
+    if "hbm_read_MB" in v and "hbm_write_MB" in v:
+        v["hbm_traffic_MB"] = v["hbm_read_MB"] + v["hbm_write_MB"]
+        if v.get("avg_active_us"):
+            v["hbm_GBps"] = v["hbm_traffic_MB"] / v["avg_active_us"] * 1e3 / 1e3
+json.dump(res, open(f"{out}/summary.json", "w"), indent=1, sort_keys=True)
+for k in sorted(res, key=lambda k: -res[k].get("total_ms", 0)):
+    v = res[k]
+    print(f"{k:22s} n={v.get('launches',0):5d} active={v.get('active_launches',0):5d} avg={v.get('avg_active_us',0):8.1f} us total={v.get('total_ms',0):8.2f} ms "
+          f"traffic={v.get('hbm_traffic_MB', float('nan')):8.1f} MB  {v.get('hbm_GBps', float('nan')):7.0f} GB/s")

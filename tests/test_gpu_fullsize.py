@@ -1,0 +1,71 @@
+"""Full-size checks at BASELINE.json's headline configuration (C4 = 512x512x20, 5.24 M nodes, F20).
+The GPU box's host is fast enough to run the oracle for hour 0 (22 steps) directly, so the first
+test is a straight comparison; the others are size-independent properties of the path:
+mass conservation, run-to-run bit-reproducibility, and idempotence of the state round trip."""
+import numpy as np
+import pytest
+
+from criteria3d_amd import capi, catchment as cm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c4():
+    return cm.catchment_model(512, 512, 20)
+
+
+def test_c4_hour0_matches_oracle(product, oracle, c4):
+    m = c4
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=64)
+    gs, gd = cm.run_hour(product, m, 20.0)
+    g = cm.snapshot(product, m)
+    os_, od = cm.run_hour(oracle, m, 20.0)
+    o = cm.snapshot(oracle, m)
+    assert gs == os_ == 22
+    np.testing.assert_allclose(gd, od, rtol=1e-12)
+    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6
+    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6
+    for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
+        assert abs(g[k] - o[k]) <= 1e-6 * max(abs(o[k]), 1e-3), (k, g[k], o[k])
+    gc, oc = product.counters(), oracle.counters()
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    oracle.lib.sf3d_clean()
+
+
+def test_c4_mass_conservation_and_reproducibility(product, c4):
+    """storage change = rain - boundary outflow to within the solver's own mass-balance threshold,
+    and two runs from the same state give bit-identical fields (deterministic reductions)."""
+    m = c4
+    runs = []
+    for _ in range(2):
+        product.check(product.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(product, m)
+        w0 = product.get_total_water_content()
+        cm.run_hour(product, m, 20.0)
+        cm.run_hour(product, m, 0.0)
+        s = cm.snapshot(product, m)
+        rain = 20e-3 * m.cell_area * m.ns                      # m3 in hour 0
+        out = s["runoff"] + s["drainage"] + s["lateral"]        # negative = leaving the domain
+        err = (s["total_water"] - w0) - (rain + out)
+        assert abs(err) <= 1e-3 * rain, (err, rain)             # MBR threshold 1e-3 per step, far smaller in sum
+        runs.append(s)
+    assert np.array_equal(runs[0]["H"], runs[1]["H"]) and np.array_equal(runs[0]["Se"], runs[1]["Se"])
+    assert runs[0]["storage"] == runs[1]["storage"]
+
+
+def test_c4_state_round_trip_is_idempotent(product, c4):
+    """getNodeTotalPotential -> setNodeTotalPotential of every node changes nothing (host staging,
+    lazy upload, pool-buffer indirection all keep H bit for bit)."""
+    m = c4
+    H = product.total_potential(0, m.n)
+    product.set_total_potential_bulk(0, H)
+    product.check(product.lib.sf3d_synchronize(), "synchronize")
+    assert np.array_equal(product.total_potential(0, m.n), H)
+    a = product.get_total_water_content()
+    product.set_total_potential_bulk(0, H)
+    assert product.get_total_water_content() == a
+    product.lib.sf3d_clean()
