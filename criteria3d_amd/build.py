@@ -59,6 +59,24 @@ def build_shim(force: bool = False) -> Path:
     return SHIM_LIB
 
 
+V1_LIB = ROOT / "shim" / "libsoilFluxes3D_v1_mi355x.so"
+
+
+def build_v1_alias(force: bool = False) -> Path:
+    """alias layer for the retired soilFluxes3D::v1 names (initializeFluxes, ...)"""
+    src = ROOT / "shim" / "sf3d_v1_alias.cpp"
+    deps = [src, ROOT / "shim" / "soilFluxes3D_v1_api.h", INCLUDE / "sf3d.h"]
+    if force or _stale(V1_LIB, deps):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", f"-I{INCLUDE}", f"-I{ROOT / 'shim'}", str(src),
+              "-o", str(V1_LIB), f"-L{CSRC}", "-lsf3d_hip", f"-Wl,-rpath,{CSRC}"])
+    demo = ROOT / "shim" / "v1_alias_demo"
+    dsrc = ROOT / "tests" / "v1_alias_demo.cpp"
+    if force or _stale(demo, [dsrc, V1_LIB]):
+        _run(["g++", "-std=c++17", "-O2", f"-I{ROOT / 'shim'}", str(dsrc), "-o", str(demo), f"-L{ROOT / 'shim'}",
+              "-lsoilFluxes3D_v1_mi355x", f"-L{CSRC}", "-lsf3d_hip", f"-Wl,-rpath,{ROOT / 'shim'}", f"-Wl,-rpath,{CSRC}"])
+    return V1_LIB
+
+
 def build_oracle(with_reference: bool = True) -> None:
     """Test infrastructure: the CPU restatement and (when /root/reference is present) oracle/_ref."""
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
@@ -69,4 +87,5 @@ def build_oracle(with_reference: bool = True) -> None:
 def build_all(force: bool = False) -> None:
     build_product(force)
     build_shim(force)
+    build_v1_alias(force)
     build_oracle()

@@ -128,6 +128,7 @@ SIGNATURES = {
     "sf3d_get_counters": (u8, [p64]),
     "sf3d_get_time_step": (f64, []),
     "sf3d_reset_solver_state": (u8, []),
+    "sf3d_set_surface_nodes_number": (u8, [u32]),
     "sf3d_set_device": (u8, [i32]),
     "sf3d_synchronize": (u8, []),
     "sf3d_kernel_timing": (u8, [i32]),

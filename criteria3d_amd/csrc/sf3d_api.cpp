@@ -538,6 +538,13 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
 }
 double sf3d_get_time_step(void) { return P.dtCurr; }
 sf3d_error_t sf3d_reset_solver_state(void) { P = ParamsHost(); M.ctrlDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_set_surface_nodes_number(uint32_t ns)
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    if (ns > M.N) return SF3D_INDEX_ERROR;
+    if (ns != M.ns) { M.ns = ns; M.graphDirty = true; }
+    return SF3D_OK;
+}
 sf3d_error_t sf3d_set_device(int d)
 {
     sf3d_error_t e = dev().set_device(d);

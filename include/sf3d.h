@@ -310,6 +310,11 @@ double sf3d_get_time_step(void);
  * "reference" backend: SF3D_MISSING_DATA_ERROR (not reachable through its public header). */
 sf3d_error_t sf3d_reset_solver_state(void);
 
+/* Declare how many of the first node indices are surface nodes when that was not known at
+ * sf3d_initialize time (the retired v1 API, old/old_soilFluxes3D.h:16, has no such argument; the
+ * v1 alias layer counts the isSurface flags of setNode and calls this before the first step). */
+sf3d_error_t sf3d_set_surface_nodes_number(uint32_t nrSurfaceNodes);
+
 /* ---- device-side instrumentation (product backend only; others return MISSING_DATA) ------ */
 
 /* Select the HIP device for this process before sf3d_initialize (default: LOCAL_RANK or 0). */

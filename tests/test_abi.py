@@ -163,3 +163,16 @@ def test_product_fails_loudly_without_a_gpu(product):
     with pytest.raises(capi.SF3DError):
         cm.build(product, cm.column_model(10))
     product.lib.sf3d_clean()
+
+
+def test_v1_alias_exports_the_retired_names():
+    """north_star names initializeFluxes/setNode/setNodeLink/computePeriod: the alias layer exports
+    them in namespace soilFluxes3D::v1 with old/old_soilFluxes3D.h's signatures."""
+    build.build_product()
+    lib = build.build_v1_alias()
+    syms = exported(lib)
+    for want in ("_ZN12soilFluxes3D2v116initializeFluxesEliibbb", "_ZN12soilFluxes3D2v17setNodeElffddbbiff",
+                 "_ZN12soilFluxes3D2v111setNodeLinkEllsf", "_ZN12soilFluxes3D2v113computePeriodEd",
+                 "_ZN12soilFluxes3D2v111computeStepEd", "_ZN12soilFluxes3D2v123getBoundaryWaterSumFlowEi"):
+        assert want in syms, want
+    assert len([s for s in syms if s.startswith("_ZN12soilFluxes3D2v1")]) == 65
