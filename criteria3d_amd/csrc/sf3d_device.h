@@ -4,7 +4,7 @@
  *
  * Data layout in HBM (all fp64 unless noted, node arrays in caller order: layer-major,
  * surface nodes first - the ordering the reference relies on):
- *   static graph   lto[10][N] u32, lkind[10][N] u8, lgeo[10][N] {area, dist}  (slot-major:
+ *   static graph   lto[10][N] u32, lkind[10][N] u8, larea[10][N], ldist[10][N]  (slot-major:
  *                  slot 0 Up, 1 Down, 2..9 laterals; consecutive threads read consecutive
  *                  nodes of one slot => coalesced), z, size, pond, cls u16, btype u8,
  *                  bslope, bsize, prescribed; per (64-node chunk, slot) descriptors ckind/cdelta
@@ -54,12 +54,15 @@ struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
 };
 
-/* per-chunk link descriptor, 64 bytes so a wave fetches it with one s_load_dwordx16 */
+/* per-chunk link descriptor (144 bytes, fetched through the scalar path once per chunk) */
 struct ChunkDesc {
     int32_t delta[SF3D_SLOTS];          /* j - i when kind[s] is a uniform link kind, else 0 */
     uint8_t kind[SF3D_SLOTS];           /* CK_NONE | LK_* (uniform) | CK_MIXED */
     uint8_t rowType;                    /* 0 all surface nodes, 1 all soil nodes, 2 straddles nrSurfaceNodes */
-    uint8_t pad[13];
+    uint8_t pad0;
+    uint16_t areaUniform;               /* bit s: every link of slot s in the chunk has interface area area[s] */
+    uint8_t pad1[10];
+    double area[SF3D_SLOTS];            /* (cell size and layer thickness make it constant over regular grids) */
 };
 
 struct BalanceDev { double storage, sinkSource, MBE, MBR; };
@@ -135,7 +138,7 @@ struct DevView {
     const double *bslope, *bsize, *prescribed;
     const uint32_t* lto;                /* [10][N] */
     const uint8_t* lkind;               /* [10][N] */
-    const sf3d_d2* lgeo;                /* [10][N] {interface area, link distance}: one 16-byte load per link */
+    const double *larea, *ldist;        /* [10][N] interface area (read only where a chunk's areas differ) and link distance */
     double* lflowSum;                   /* [10][N] */
     sf3d_d2* A2;                        /* [5][N] row-normalised off-diagonals, slots paired (2p, 2p+1): 16-byte accesses */
     double *b, *C;

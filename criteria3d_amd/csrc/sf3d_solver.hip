@@ -170,7 +170,7 @@ __device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c,
                 rate = -dmin(val, maxFlow);
                 break; }
             case SF3D_BND_FREE_DRAINAGE:                              /* :680-684, Up-link area */
-                rate = -K * v.lgeo[i].x;
+                rate = -K * v.larea[i];
                 break;
             case SF3D_BND_FREE_LATERAL_DRAINAGE:                      /* :686-690 */
                 rate = -K * v.bsize[i] * v.bslope[i] * c->lvRatio;
@@ -564,8 +564,7 @@ __device__ __forceinline__ double infiltration_conductance(const DevView& v, con
                                                            const double* __restrict__ Xc, const double* __restrict__ Xh,
                                                            double Hi, double Hoi, double zi)
 {
-    const sf3d_d2 geo = v.lgeo[e];
-    const double area = geo.x, dist = geo.y;
+    const double area = v.larea[e], dist = v.ldist[e];
     const double dt = c->dt;
     const bool iSurf = i < v.ns;
     const uint32_t su = iSurf ? i : j, so = iSurf ? j : i;
@@ -601,8 +600,7 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
                                                    const double* __restrict__ Xh, double Hi, double Hoi,
                                                    double zi, double& courant)
 {
-    const sf3d_d2 geo = v.lgeo[e];
-    const double area = geo.x, dist = geo.y;
+    const double area = v.larea[e], dist = v.ldist[e];
     const double dt = c->dt;
     if (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT) {
         double ki = v.K[i], kj = v.K[j];
@@ -725,7 +723,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(De
                     const size_t e = (size_t)s * v.N + i;
                     if (cd.kind[s] == CK_MIXED) { kd[t] = v.lkind[e]; j[t] = v.lto[e]; }
                     else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
-                    const sf3d_d2 geo = v.lgeo[e]; area[t] = geo.x; dist[t] = geo.y;
+                    area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : v.larea[e];
+                    dist[t] = v.ldist[e];
                 }
             }
             #pragma unroll
@@ -1113,7 +1112,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         /* derived static graph data: link kind and link distance (host, libm - exactly the
          * reference's nodeDistance2D/3D arithmetic, soilPhysics.cpp:328-338) */
         std::vector<uint8_t> kind(NS, LK_NONE);
-        std::vector<sf3d_d2> geo(NS, sf3d_d2{0., 0.});
+        std::vector<double> dist(NS, 0.), area(NS, 0.);
         std::vector<uint32_t> to(NS, 0u);
         bool bad = false;
         parallel_for(N, [&](uint32_t a, uint32_t b) {
@@ -1124,24 +1123,24 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (m.ltype[s][i] == SF3D_LINK_NONE) continue;
                     const uint32_t j = m.lto[s][i];
                     const size_t e = (size_t)s * N + i;
-                    to[e] = j; geo[e].x = m.larea[s][i];
+                    to[e] = j; area[e] = m.larea[s][i];
                     const bool si = i >= ns, sj = j >= ns;
                     if (si && sj) {
                         if (m.ltype[s][i] == SF3D_LINK_LATERAL) {
                             kind[e] = LK_SOIL_LAT;
                             const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j], dz = m.z[i] - m.z[j];
                             double nrm = 0; nrm += dx * dx; nrm += dy * dy; nrm += dz * dz;
-                            geo[e].y = std::sqrt(nrm);
-                        } else { kind[e] = LK_SOIL_VERT; geo[e].y = std::fabs(m.z[i] - m.z[j]); }
+                            dist[e] = std::sqrt(nrm);
+                        } else { kind[e] = LK_SOIL_VERT; dist[e] = std::fabs(m.z[i] - m.z[j]); }
                     } else if (!si && !sj) {
                         kind[e] = LK_RUNOFF;
                         const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j];
                         double nrm = 0; nrm += dx * dx; nrm += dy * dy;
-                        geo[e].y = std::sqrt(nrm);
+                        dist[e] = std::sqrt(nrm);
                     } else {
                         kind[e] = LK_INFILTRATION;
                         const uint32_t su = sj ? i : j, so = sj ? j : i;
-                        geo[e].y = m.z[su] - m.z[so];
+                        dist[e] = m.z[su] - m.z[so];
                     }
                 }
                 if (m.btype[i] == SF3D_BND_FREE_DRAINAGE && m.ltype[0][i] == SF3D_LINK_NONE) bad = true;   /* assert water.cpp:682 */
@@ -1173,6 +1172,16 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (any) ck = (all && same && d0 >= INT32_MIN && d0 <= INT32_MAX) ? k0 : (uint8_t)CK_MIXED;
                     d.kind[s] = ck;
                     d.delta[s] = (ck != CK_NONE && ck != CK_MIXED) ? (int32_t)d0 : 0;
+                    if (any) {                                   /* one interface area for the whole chunk? */
+                        bool first = true, uni = true; double a0 = 0.;
+                        for (uint32_t i = i0; i < i1 && uni; ++i) {
+                            const size_t e = (size_t)s * N + i;
+                            if (kind[e] == LK_NONE) continue;
+                            if (first) { a0 = area[e]; first = false; }
+                            else if (area[e] != a0) uni = false;
+                        }
+                        if (uni) { d.areaUniform |= (uint16_t)(1u << s); d.area[s] = a0; }
+                    }
                 }
                 cdesc[q] = d;
             }
@@ -1204,7 +1213,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
 
-        double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness; sf3d_d2* lgeo;
+        double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness, *larea, *ldist;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
         HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
         HIP_TRY(dev_alloc(I.allocs, pond, N)); HIP_TRY(dev_alloc(I.allocs, sink, N));
@@ -1212,7 +1221,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, bslope, N)); HIP_TRY(dev_alloc(I.allocs, bsize, N));
         HIP_TRY(dev_alloc(I.allocs, prescribed, N));
         HIP_TRY(dev_alloc(I.allocs, lto, NS)); HIP_TRY(dev_alloc(I.allocs, lkind, NS));
-        HIP_TRY(dev_alloc(I.allocs, lgeo, NS));
+        HIP_TRY(dev_alloc(I.allocs, larea, NS)); HIP_TRY(dev_alloc(I.allocs, ldist, NS));
         HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A2, NS / 2));
         HIP_TRY(dev_alloc(I.allocs, v.b, N)); HIP_TRY(dev_alloc(I.allocs, v.C, N));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
@@ -1263,7 +1272,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
         v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
         v.bslope = bslope; v.bsize = bsize; v.prescribed = prescribed;
-        v.lto = lto; v.lkind = lkind; v.lgeo = lgeo; v.soils = soils; v.roughness = roughness;
+        v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
         v.cdesc = dcdesc;
 
         std::vector<SoilDev> sd(m.soils.size());
@@ -1276,7 +1285,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpy(cls, m.cls.data(), N * 2, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lto, to.data(), NS * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lkind, kind.data(), NS, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(lgeo, geo.data(), NS * sizeof(sf3d_d2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(larea, area.data(), NS * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ldist, dist.data(), NS * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dcdesc, cdesc.data(), cdesc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
         if (!sd.empty()) HIP_TRY(hipMemcpy(soils, sd.data(), sd.size() * sizeof(SoilDev), hipMemcpyHostToDevice));
         if (!m.roughness.empty()) HIP_TRY(hipMemcpy(roughness, m.roughness.data(), m.roughness.size() * 8, hipMemcpyHostToDevice));
