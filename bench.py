@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -177,7 +178,7 @@ def main():
         fresh()
 
     # HIP events around the dominant kernel only (mode 2); --time-all-kernels instruments every node kernel
-    sf.check(sf.lib.sf3d_kernel_timing(1 if args.time_all_kernels else 2), "kernel_timing")
+    sf.check(sf.lib.sf3d_kernel_timing(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2)), "kernel_timing")
     per_step, hour_starts = [], []
     barrier()
     torch.cuda.synchronize()

@@ -37,13 +37,13 @@ enum : uint8_t { LK_NONE = 0, LK_SOIL_VERT = 1, LK_SOIL_LAT = 2, LK_RUNOFF = 3, 
 /* stages of the device-resident step state machine (cpusolver.cpp:143-190, 392-468) */
 enum : uint32_t {
     ST_IDLE = 0,        /* between computeStep calls                                         */
-    ST_ATTEMPT = 1,     /* begin an attempt: dt = min(dtCurr, max), Hold = H                 */
+    ST_ATTEMPT = 1,     /* (unused: an attempt begins inline in k_step_begin / on rejection)   */
     ST_APPROX = 2,      /* properties + boundary + assembly of approximation `approx`        */
     ST_SWEEP = 3,       /* Jacobi sweeps running                                             */
     ST_POST = 4,        /* H = x, Se, balance sums                                           */
     ST_RESTORE = 5,     /* restoreBestStep: H = Hbest, Se, K, boundary, balance              */
-    ST_ACCEPT = 6,      /* acceptStep: flow sums                                             */
-    ST_DONE = 7,        /* step accepted                                                     */
+    ST_ACCEPT = 6,      /* step accepted: bookkeeping done, k_accept adds the flow sums        */
+    ST_DONE = 7,        /* (unused)                                                          */
     ST_FAIL = 8         /* stepNan                                                           */
 };
 

@@ -308,16 +308,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sync_kf(DevView v)
 /* control kernels (one thread / one block)                                                 */
 /* ======================================================================================= */
 
-__global__ void k_step_begin(Ctrl* c, double maxTimeStep)
-{
-    c->maxTimeStep = maxTimeStep;
-    c->stage = ST_ATTEMPT;
-}
-
 /* waterMainLoop body head, cpusolver.cpp:155-162 (Hold = H is an index copy) */
-__global__ void k_attempt_begin(Ctrl* c)
+__device__ __forceinline__ void begin_attempt(Ctrl* c)
 {
-    if (c->stage != ST_ATTEMPT) return;
     c->dt = dmin(c->dtCurr, c->maxTimeStep);
     c->hold = c->cur;
     c->best = -1;
@@ -327,11 +320,17 @@ __global__ void k_attempt_begin(Ctrl* c)
     c->stage = ST_APPROX;
 }
 
-__device__ __forceinline__ void reject_attempt(Ctrl* c)     /* cpusolver.cpp:182-186 */
+__global__ void k_step_begin(Ctrl* c, double maxTimeStep)
+{
+    c->maxTimeStep = maxTimeStep;
+    begin_attempt(c);
+}
+
+/* a refused attempt restores H = Hold (cpusolver.cpp:182-186) and the loop starts the next one */
+__device__ __forceinline__ void reject_attempt(Ctrl* c)
 {
     c->cur = c->hold;
-    c->best = -1;
-    c->stage = ST_ATTEMPT;
+    begin_attempt(c);
 }
 
 /* checkCourant, cpusolver.cpp:248-281, then the iteration budget of solver.h:55-59 */
@@ -418,7 +417,8 @@ __device__ __forceinline__ void accept_bookkeeping(Ctrl* c)
     c->prevStep.storage = c->curStep.storage;
     c->prevStep.sinkSource = c->curStep.sinkSource;
     c->curPeriod.sinkSource += c->curStep.sinkSource;
-    c->stage = ST_ACCEPT;
+    c->counters[1]++;
+    c->stage = ST_ACCEPT;              /* k_accept (flow sums) is the last kernel of the step */
 }
 __device__ __forceinline__ void halve_and_reject(Ctrl* c)
 {
@@ -474,13 +474,6 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_restore(DevView v)
     c->counters[6]++;
     mass_balance(c, storage, sink);
     accept_bookkeeping(c);
-}
-
-__global__ void k_decide_accept(Ctrl* c)
-{
-    if (c->stage != ST_ACCEPT) return;
-    c->counters[1]++;
-    c->stage = ST_DONE;
 }
 
 __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
@@ -653,7 +646,7 @@ __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd,
 
 /* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
  * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
-__global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
+__device__ __forceinline__ void assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
@@ -662,7 +655,10 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
     const double dt = c->dt;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     double courant = 0.;
-    FOR_EACH_CHUNK_IN(v, 0u, v.nListSurf) {
+    const uint32_t lane_ = threadIdx.x & 63u;
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nListSurf;
+         li_ += nblk * (SF3D_BLOCK / 64)) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(v.chunkList[li_]);
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];
@@ -686,7 +682,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
         store_row(v, cd, i, k, sum, Hoi, dt);
     }
     const double bm = block_max(courant);
-    if (threadIdx.x == 0) v.part0[blockIdx.x] = bm;
+    if (threadIdx.x == 0) v.part0[blk] = bm;
 }
 
 /* rows of the soil-only chunks [qSplit, nChunks).  Two groups of five slots: all index / area /
@@ -695,16 +691,18 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_assemble_surface(DevView v)
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
-__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(DevView v)
+__device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_APPROX) return;
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
     const double dt = c->dt, lvRatio = c->lvRatio;
     const uint32_t meanType = c->meanType;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-    FOR_EACH_CHUNK_IN(v, v.nListSurf, v.nList) {
+    const uint32_t lane_ = threadIdx.x & 63u;
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nListSurf + blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nList;
+         li_ += nblk * (SF3D_BLOCK / 64)) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(v.chunkList[li_]);
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
@@ -747,6 +745,15 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble_soil(De
         }
         store_row(v, cd, i, k, sum, Hoi, dt);
     }
+}
+
+/* one launch: blocks [0, nbSurf) assemble the surface rows (and reduce the Courant maximum),
+ * blocks [nbSurf, nbSurf + nbSoil) the soil rows */
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView v)
+{
+    if (v.ctrl->stage != ST_APPROX) return;
+    if (blockIdx.x < v.nbSurf) assemble_surface_rows(v, blockIdx.x, v.nbSurf);
+    else assemble_soil_rows(v, blockIdx.x - v.nbSurf, v.nbSoil);
 }
 
 /* JacobiWaterCPU, water.cpp:565-601.
@@ -993,6 +1000,10 @@ struct DeviceSolver::Impl {
     std::vector<void*> allocs;
     uint32_t N = 0, ns = 0;
     uint32_t lastSweeps = 8;
+    uint32_t lastBatches = 1;
+    /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
+    std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
+    int useGraphs = -1;                    /* -1 unknown, 0 off (SF3D_GRAPHS=0), 1 on */
     /* multi-GPU */
     Partition part;
     DistWindow* window = nullptr;          /* fine-grained, IPC-exported */
@@ -1037,6 +1048,8 @@ sf3d_error_t DeviceSolver::release()
     if (I.stream) hipStreamSynchronize(I.stream);
     for (auto& p : I.pending) { I.freeEvents.push_back(p.a); I.freeEvents.push_back(p.b); }
     I.pending.clear();
+    for (auto& g : I.graphs) hipGraphExecDestroy(g.second);
+    I.graphs.clear();
     for (void* p : I.allocs) hipFree(p);
     I.allocs.clear();
     for (void* p : I.peerMaps) hipIpcCloseMemHandle(p);
@@ -1470,22 +1483,21 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     };
 
     hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
-    uint32_t stage = ST_ATTEMPT;
-    uint64_t before[8];
+    uint32_t stage = ST_APPROX;             /* k_step_begin opens the first attempt */
+    uint64_t before[8], atStart[8];
     std::memcpy(before, mirror_.counters, sizeof(before));
+    std::memcpy(atStart, mirror_.counters, sizeof(atStart));
     int guard = 0;
-    while (true) {
-        if (stage == ST_ATTEMPT || stage == ST_APPROX) {
-            hipLaunchKernelGGL(k_attempt_begin, one, one, 0, st, v.ctrl);
+
+    /* one approximation's worth of guarded kernels */
+    auto enqueue_batch = [&](bool withHead, bool withTail) {
+        if (withHead) {
             timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props, grid, block, 0, st, v); });
             if (multi) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
-            timed(KID_ASSEMBLE, [&] {
-                hipLaunchKernelGGL(k_assemble_surface, dim3(v.nbSurf), block, 0, st, v);
-                if (v.nbSoil) hipLaunchKernelGGL(k_assemble_soil, dim3(v.nbSoil), block, 0, st, v);
-            });
+            timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL(k_assemble, dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
         }
         uint32_t chunk = I.lastSweeps + 2;
@@ -1498,41 +1510,80 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         }
         timed(KID_POST, [&] { hipLaunchKernelGGL(k_post, grid, block, 0, st, v); });
         hipLaunchKernelGGL(k_decide_balance, one, block, 0, st, v);
-        timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore, grid, block, 0, st, v); });
-        hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
-        timed(KID_ACCEPT, [&] { hipLaunchKernelGGL(k_accept, grid, block, 0, st, v); });
-        hipLaunchKernelGGL(k_decide_accept, one, one, 0, st, v.ctrl);
+        if (withTail) {     /* restore-best and the flow sums of the accepted step: once per poll group */
+            timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore, grid, block, 0, st, v); });
+            hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
+            timed(KID_ACCEPT, [&] { hipLaunchKernelGGL(k_accept, grid, block, 0, st, v); });
+        }
+    };
+
+    /* Look-ahead: the previous step needed `lastBatches` approximations; queue that many guarded
+     * batches before the first poll (a batch queued in vain costs ~25 no-op launches, a poll costs
+     * a full host round trip while the GPU idles).  After the first poll continue one at a time. */
+    /* The ~25 launches of a batch are replayed from an instantiated hipGraph (one per shape): small
+     * grids are bound by the host's launch rate otherwise.  Event timing needs eager launches. */
+    if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
+    auto launch_batch = [&](bool withHead, bool withTail) -> hipError_t {
+        if (!I.useGraphs || I.timing) { enqueue_batch(withHead, withTail); return hipSuccess; }
+        uint32_t chunk = I.lastSweeps + 2;
+        if (chunk < 4) chunk = 4;
+        if (chunk > 40) chunk = 40;
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2);
+        for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) return e;
+        enqueue_batch(withHead, withTail);
+        e = hipStreamEndCapture(st, &graph);
+        if (e != hipSuccess) return e;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e != hipSuccess) return e;
+        I.graphs.push_back({key, exec});
+        return hipGraphLaunch(exec, st);
+    };
+
+    uint32_t look = I.lastBatches < 1 ? 1 : (I.lastBatches > 6 ? 6 : I.lastBatches);
+    while (true) {
+        for (uint32_t bq = 0; bq < look; ++bq)
+            HIP_TRY(launch_batch(bq > 0 || stage == ST_APPROX, bq + 1 == look));
+        look = 1;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const Ctrl& c = *I.hostCtrl;
 
         if (I.timing) {
-            /* attribute event pairs only to launches that really ran (guarded no-ops excluded):
-             * executed counts per kernel come from the device counters */
+            /* attribute event pairs only to launches that really ran: how many of each kernel ran
+             * comes from the device counters; guarded no-op launches are the shortest of a group */
             uint64_t ran[KID_COUNT];
             ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
             ran[KID_SWEEP] = c.counters[3] - before[3];
             ran[KID_POST] = c.counters[7] - before[7];
             ran[KID_RESTORE] = c.counters[6] - before[6];
             ran[KID_ACCEPT] = c.counters[1] - before[1];
+            std::vector<float> el[KID_COUNT];
             for (auto& pr : I.pending) {
-                if (ran[pr.kid] > 0) {
-                    float t = 0.f;
-                    if (hipEventElapsedTime(&t, pr.a, pr.b) == hipSuccess) { I.ms[pr.kid] += t; I.launches[pr.kid]++; }
-                    ran[pr.kid]--;
-                }
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, pr.a, pr.b) == hipSuccess) el[pr.kid].push_back(t);
                 I.freeEvents.push_back(pr.a); I.freeEvents.push_back(pr.b);
             }
             I.pending.clear();
+            for (int k = 0; k < KID_COUNT; ++k) {
+                std::sort(el[k].begin(), el[k].end(), [](float x, float y) { return x > y; });
+                for (size_t q = 0; q < el[k].size() && q < ran[k]; ++q) { I.ms[k] += el[k][q]; I.launches[k]++; }
+            }
         }
         std::memcpy(before, c.counters, sizeof(before));
 
         stage = c.stage;
-        if (stage == ST_POST || stage == ST_DONE || stage == ST_FAIL || stage == ST_APPROX || stage == ST_ATTEMPT)
-            if (c.iter > 0) I.lastSweeps = c.iter;
-        if (stage == ST_DONE || stage == ST_FAIL) break;
+        if (stage != ST_SWEEP && c.iter > 0) I.lastSweeps = c.iter;
+        if (stage == ST_ACCEPT || stage == ST_FAIL) break;   /* ST_ACCEPT: bookkeeping done and k_accept has run */
         if (++guard > 1000000) { snprintf(err_, sizeof(err_), "step state machine did not terminate (stage %u)", stage); return SF3D_SOLVER_ERROR; }
+    }
+    {   /* approximations this step took (rejected attempts included) = batches the next one will queue up front */
+        const uint64_t used = I.hostCtrl->counters[2] - atStart[2];
+        I.lastBatches = used < 1 ? 1u : (uint32_t)used;
     }
     mirror_ = *I.hostCtrl;
     if (mirror_.distError) snprintf(err_, sizeof(err_), "rank %d: a peer did not answer within the bounded wait (multi-GPU exchange)", rank_);
@@ -1540,5 +1591,5 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     *dtOut = mirror_.dt;
     m.hostStaleState = true;
     m.hostStaleFlows = true;
-    return (stage == ST_DONE) ? SF3D_OK : SF3D_SOLVER_ERROR;
+    return (stage == ST_ACCEPT) ? SF3D_OK : SF3D_SOLVER_ERROR;
 }
