@@ -145,6 +145,7 @@ struct DevView {
     double* X[SF3D_POOL];
     double *Se, *SeHold, *K, *flow, *bflowRate, *bflowSum;   /* SeHold = Se(Hold), written at approximation 0 */
     double *part0, *part1;              /* per-block partials [nb] */
+    unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
     const SoilDev* soils;
     const double* roughness;
     Ctrl* ctrl;

@@ -363,18 +363,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_courant(DevView v)
     reject_attempt(c);
 }
 
-/* solveLinearSystem loop control, cpusolver.cpp:672-703 + :442-447 */
-__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
+/* solveLinearSystem loop control, cpusolver.cpp:672-703 + :442-447 (one thread) */
+__device__ __forceinline__ void sweep_decision(Ctrl* c, int nxt, double norm)
 {
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP) return;
-    const int nxt = free_buffer(c);              /* the buffer k_sweep wrote */
-    const uint32_t par = c->epoch & 1u;
-    double vals[3] = {reduce_partials_sum(v.part0, v.nb), 0., 0.};
-    if (!dist_allgather(v, c, vals, 0)) return;
-    if (v.world > 1) dist_unpack(v, par, 0, v.X[nxt]);     /* neighbours' new iterate on my halo */
-    if (threadIdx.x != 0) return;
-    const double norm = vals[0] / v.N;
     c->cur = nxt;                     /* std::swap(vectorNewX, vectorX), water.cpp:598 */
     c->iter++;
     c->counters[3]++;
@@ -394,6 +385,19 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
         reject_attempt(c);
     } else
         c->stage = ST_POST;
+}
+
+__global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP) return;
+    const int nxt = free_buffer(c);              /* the buffer k_sweep wrote */
+    const uint32_t par = c->epoch & 1u;
+    double vals[3] = {reduce_partials_sum(v.part0, v.nb), 0., 0.};
+    if (!dist_allgather(v, c, vals, 0)) return;
+    if (v.world > 1) dist_unpack(v, par, 0, v.X[nxt]);     /* neighbours' new iterate on my halo */
+    if (threadIdx.x != 0) return;
+    sweep_decision(c, nxt, vals[0] / v.N);
 }
 
 /* computeCurrentMassBalance, water.cpp:96-123 */
@@ -759,6 +763,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView
 /* JacobiWaterCPU, water.cpp:565-601.
  * All coefficient loads, then all neighbour gathers, are issued before the ordered accumulation
  * so that ~30 independent loads per lane are in flight (HBM-bound kernel, 152 algorithmic B/node). */
+template <bool FUSED>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -798,7 +803,41 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
         xout[i] = xn;
     }
     const double bs = block_sum(nrm);
-    if (threadIdx.x == 0) v.part0[blockIdx.x] = bs;
+    if (!FUSED) {
+        if (threadIdx.x == 0) v.part0[blockIdx.x] = bs;
+        return;
+    }
+    /* Single GPU: the block that arrives last reduces the partials (fixed order) and takes the
+     * convergence decision, saving one launch per sweep.  Hand-off per MI355X_MICROARCH.md
+     * "Valid forms": one lane per block stores its partial write-through (sc1), drains it, then
+     * adds to an agent-scope counter; the block whose add returns nb-1 reads the partials with sc1
+     * loads.  Nothing else crosses blocks inside the launch (xout is read by the NEXT kernel). */
+    __shared__ int sLast;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&v.part0[blockIdx.x], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        /* two-level arrival (16 shard counters on separate lines, then one top counter): a single
+         * counter serialises ~12 ns per block, 25 us for 2048 blocks */
+        const unsigned int shard = blockIdx.x & 15u;
+        const unsigned int inShard = (gridDim.x + 15u - shard) >> 4;
+        const unsigned int shards = gridDim.x < 16u ? gridDim.x : 16u;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&v.arrive[16u * (shard + 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inShard - 1u) {
+            __hip_atomic_store(&v.arrive[16u * (shard + 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(&v.arrive[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u;
+        }
+        sLast = last;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    double s = 0.;
+    for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK)
+        s += __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double total = block_sum(s);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(v.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sweep_decision(v.ctrl, free_buffer(c), total / v.N);
+    }
 }
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
@@ -1003,6 +1042,7 @@ struct DeviceSolver::Impl {
     uint32_t lastBatches = 1;
     /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
+    int useFused = -1;                     /* SF3D_FUSED_DECIDE=0 keeps the separate decision kernel */
     int useGraphs = -1;                    /* -1 unknown, 0 off (SF3D_GRAPHS=0), 1 on */
     /* multi-GPU */
     Partition part;
@@ -1281,6 +1321,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
         HIP_TRY(dev_alloc(I.allocs, v.part0, v.nb)); HIP_TRY(dev_alloc(I.allocs, v.part1, v.nb));
+        HIP_TRY(dev_alloc(I.allocs, v.arrive, 16 * 17)); HIP_TRY(hipMemset(v.arrive, 0, 16 * 17 * sizeof(unsigned int)));
         HIP_TRY(dev_alloc(I.allocs, soils, m.soils.size())); HIP_TRY(dev_alloc(I.allocs, roughness, m.roughness.size()));
         HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
         v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
@@ -1470,6 +1511,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const DevView& v = I.v;
     const dim3 grid(v.nb), block(SF3D_BLOCK), one(1);
     const bool multi = world_ > 1;
+    if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
+    const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
@@ -1504,7 +1547,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
         for (uint32_t k = 0; k < chunk; ++k) {
-            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep, grid, block, 0, st, v); });
+            if (fused) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<true>, grid, block, 0, st, v); }); continue; }
+            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<false>, grid, block, 0, st, v); });
             if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }

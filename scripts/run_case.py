@@ -1,0 +1,30 @@
+"""Run one scenario on the HIP product and save H/Se/dts (used by tests that compare library modes
+selected through environment variables, which the library reads once per process).
+usage: python scripts/run_case.py <case> <outfile>"""
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np
+from criteria3d_amd import capi, catchment as cm
+
+case, out = sys.argv[1], sys.argv[2]
+sf = capi.load_product()
+if case == "c2f60":
+    m, plan = cm.catchment_model(64, 64, 10), [(60.0, None), (0.0, 600)]
+elif case == "c3f20":
+    m, plan = cm.catchment_model(256, 256, 15), [(20.0, None), (0.0, None)]
+elif case == "c4f20":
+    m, plan = cm.catchment_model(512, 512, 20), [(20.0, None)]
+else:
+    raise SystemExit("unknown case")
+sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+cm.build(sf, m)
+res = {}
+for h, (mm, mx) in enumerate(plan):
+    _, dts = cm.run_hour(sf, m, mm, max_steps=mx)
+    s = cm.snapshot(sf, m)
+    res[f"H{h}"] = s["H"]; res[f"Se{h}"] = s["Se"]; res[f"dts{h}"] = np.array(dts); res[f"storage{h}"] = np.array(s["storage"])
+c = sf.counters()
+res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
+np.savez(out, **res)
+sf.lib.sf3d_clean()

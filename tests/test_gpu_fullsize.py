@@ -69,3 +69,27 @@ def test_c4_state_round_trip_is_idempotent(product, c4):
     product.set_total_potential_bulk(0, H)
     assert product.get_total_water_content() == a
     product.lib.sf3d_clean()
+
+
+@pytest.mark.parametrize("case", ["c2f60", "c3f20", "c4f20"])
+def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
+    """The single-GPU fast path (sweep + convergence decision fused through a last-block hand-off,
+    batches replayed from hipGraphs) must give exactly the bits of the plain path (separate
+    decision kernel, eager launches): same partial-sum order, same decisions."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    outs = []
+    for fused, graphs in (("1", "1"), ("0", "0")):
+        out = tmp_path / f"{case}_{fused}{graphs}.npz"
+        env = dict(os.environ, SF3D_FUSED_DECIDE=fused, SF3D_GRAPHS=graphs)
+        p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs.append(np.load(out))
+    a, b = outs
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
