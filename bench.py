@@ -65,7 +65,7 @@ def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None):
     return total
 
 
-def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0):
+def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0, threads=32):
     """Reference CPU/OpenMP path on a bounded sample: computeStep calls from the same initial
     state until `budget_s` seconds of CPU work are spent (at least one step)."""
     kind, sf = "port", None
@@ -75,7 +75,14 @@ def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20
     except Exception as e:  # noqa: BLE001  (missing Qt on the box, or oracle/_ref not built)
         log(f"[bench] oracle/_ref not loadable ({e}); timing the oracle port instead")
         sf = capi.load_oracle()
-    cores = os.cpu_count() or 1
+    # profiles/r01_cpu_baselines.json: on this class of host the reference's OpenMP path is fastest with
+    # 16-32 threads (C4 hour 0: 12.6 s at 32, 17.3 s at 64) and collapses when every logical CPU is used
+    # (256 threads: 50x slower), so the baseline uses `threads`, not os.cpu_count()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(threads, avail))
     if kind == "port":
         sf.lib.sf3d_reset_solver_state()
     t_build = time.perf_counter()
@@ -116,6 +123,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (best measured: 16-32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -230,7 +238,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(cm, capi, model, args.forcing, args.workload,
-                               (hour_starts[0], per_step) if hour_starts else None, budget_s=args.cpu_budget)
+                               (hour_starts[0], per_step) if hour_starts else None, budget_s=args.cpu_budget,
+                               threads=args.cpu_threads)
         except Exception as e:  # noqa: BLE001
             log(f"[bench] cpu_baseline failed: {e}")
 

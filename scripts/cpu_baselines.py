@@ -1,0 +1,56 @@
+"""CPU baselines on the GPU box's host (SURVEY.md 8d "CPU baseline timing"): the unmodified
+reference (oracle/_ref, project flags -O2 -fopenmp) driven through the same harness, one fresh
+process per measurement.  usage: python scripts/cpu_baselines.py [outfile]"""
+import json, os, subprocess, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+WORKER = r'''
+import sys, time, os
+sys.path.insert(0, %r)
+import numpy as np
+from criteria3d_amd import capi, catchment as cm
+backend, nx, ny, nz, forcing, hours, threads, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), float(sys.argv[8])
+sf = capi.load_reference() if backend == "reference" else capi.load_oracle()
+m = cm.catchment_model(nx, ny, nz)
+cm.build(sf, m, threads=threads)
+used = int(sf.lib.sf3d_set_threads_number(threads))
+sim = wall = 0.0; steps = 0
+for h in range(hours):
+    sf.set_sink_source_bulk(0, np.full(m.ns, cm.rain_rate(cm.FORCINGS[forcing](h), m.cell_area)))
+    t = 0.0
+    while t < 3600.0 and wall < budget:
+        t0 = time.perf_counter(); dt = sf.lib.sf3d_compute_step(3600.0 - t); wall += time.perf_counter() - t0
+        t += dt; sim += dt; steps += 1
+    if wall >= budget: break
+print("RESULT", used, steps, sim, wall)
+''' % str(ROOT)
+
+def run(backend, shape, forcing, hours, threads, budget=60.0):
+    p = subprocess.run([sys.executable, "-c", WORKER, backend, *map(str, shape), forcing, str(hours), str(threads), str(budget)],
+                       capture_output=True, text=True, timeout=1200)
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+    if not line:
+        return {"error": (p.stdout + p.stderr)[-400:]}
+    used, steps, sim, wall = line[0].split()[1:]
+    return {"backend": backend, "grid": "x".join(map(str, shape)), "forcing": forcing, "threads": int(used), "steps": int(steps),
+            "simulated_s": float(sim), "wall_s": float(wall), "sim_h_per_s": float(sim) / 3600.0 / float(wall)}
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cpu_baselines.json"
+    ncpu = os.cpu_count() or 1
+    res = {"host_threads": ncpu, "cpu_model": next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "runs": []}
+    for backend in ("reference",):
+        for threads in (1, 16, 64, ncpu):
+            res["runs"].append(run(backend, (64, 64, 10), "F20", 6, threads))
+        for threads in (16, 64, ncpu):
+            res["runs"].append(run(backend, (256, 256, 15), "F20", 2, threads, budget=40.0))
+        for threads in (32, 64, ncpu):
+            res["runs"].append(run(backend, (512, 512, 20), "F20", 1, threads, budget=25.0))
+    json.dump(res, open(out, "w"), indent=1)
+    for r in res["runs"]:
+        print(r)
+
+if __name__ == "__main__":
+    main()
