@@ -203,7 +203,7 @@ __device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c,
 
 /* One block.  All-gather of up to three doubles per rank through the peers' windows, combined in
  * rank order (identical bits on every rank).  op 0 = sum, 1 = max.  Advances the epoch.
- * Returns false (and raises distError / ST_FAIL) when a peer does not answer within ~10 s. */
+ * Returns false (and raises distError / ST_FAIL) when a peer does not answer within 60 s. */
 __device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double (&vals)[3], int op)
 {
     if (v.world <= 1) return true;
@@ -228,7 +228,7 @@ __device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double
             DistMail* m = &d->win[v.rank]->mail[par][p];
             while (__hip_atomic_load(&m->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
                 __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 1000000000LL) { ok = false; break; }
+                if (wall_clock64() - t0 > 6000000000LL) { ok = false; break; }   /* 60 s at 100 MHz */
             }
             if (!ok) break;
             for (int k = 0; k < 3; ++k) {
