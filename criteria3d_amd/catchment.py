@@ -326,3 +326,109 @@ def run_hour_sinks(sf: capi.SF3D, m: Model, sinks: np.ndarray, max_steps: int | 
         if max_steps is not None and len(dts) >= max_steps:
             break
     return len(dts), dts
+
+
+def dem_layer_thicknesses(depth: float = 0.95, first: float = 0.02, maximum: float = 0.10, reach: float = 0.40):
+    """Soil layer thicknesses as the caller builds them (src/project3D/project3D.cpp:1568-1661):
+    geometric growth from `first` so that `maximum` is reached at depth `reach`, then constant,
+    the last layer taking the remainder."""
+    best = None
+    for k in range(101, 201):
+        g = k / 100.0
+        t, z = first, 0.0
+        while t < maximum:                  # depth at which the growing thickness reaches the maximum
+            z += t; t *= g
+        if best is None or abs(z - reach) < best[0]:
+            best = (abs(z - reach), g)
+    g = best[1]
+    out, t, z = [], first, 0.0
+    while z < depth - 1e-9:
+        t_eff = min(t, maximum, depth - z)
+        if depth - (z + t_eff) < 0.5 * first:       # the last layer takes the remainder
+            t_eff = depth - z
+        out.append(t_eff); z += t_eff; t = min(t * g, maximum)
+    return out
+
+
+def dem_model(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, depth: float = 0.95, lv_ratio: float = 4.0,
+              n_soils: int = 3) -> Model:
+    """Graph of a real DEM window the way the caller builds it: surface layer first,
+    nodes only where the DEM is valid, soil columns cut where the local soil depth ends, z and the
+    boundary slope rounded through float32 like `setCrit3DTopography` (project3D.cpp:949-1010),
+    runoff outlets on DEM-edge cells that are local minima or slope outwards, FreeDrainage under the
+    last soil node of each column, FreeLateralDrainage on the edge columns."""
+    ny, nx = dem.shape
+    valid = dem != nodata
+    thick = dem_layer_thicknesses(depth)
+    nz = len(thick) + 1
+    centre = np.cumsum(thick) - 0.5 * np.array(thick)
+    bottom = np.cumsum(thick)
+    # local soil depth: full depth on gentle slopes, shallower on steep ones (deterministic from the DEM)
+    gy, gx = np.gradient(np.where(valid, dem, np.nan).astype(np.float64), cell)
+    slope = np.sqrt(np.nan_to_num(gx) ** 2 + np.nan_to_num(gy) ** 2)
+    soil_depth = np.clip(depth * (1.0 - 0.8 * np.clip(slope, 0, 1)), 0.25, depth)
+    index = -np.ones((nz, ny, nx), np.int64)
+    n = 0
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                if valid[r, c] and (l == 0 or bottom[l - 1] <= soil_depth[r, c] + 1e-9 or l == 1):
+                    index[l, r, c] = n; n += 1
+    ns = int(valid.sum())
+    area = cell * cell
+    x = np.zeros(n); y = np.zeros(n); z = np.zeros(n); size = np.zeros(n)
+    surf = np.zeros(n, np.uint8); btype = np.zeros(n, np.uint8); bslope = np.zeros(n); barea = np.zeros(n)
+    soil_index = np.zeros(n - ns, np.uint16)
+    edge = np.zeros((ny, nx), bool)
+    for r in range(ny):
+        for c in range(nx):
+            if not valid[r, c]:
+                continue
+            for dr, dc in LATERAL_OFFSETS:
+                rr, cc = r + dr, c + dc
+                if rr < 0 or rr >= ny or cc < 0 or cc >= nx or not valid[rr, cc]:
+                    edge[r, c] = True
+    ln, lt, ld, la = [], [], [], []
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                i = index[l, r, c]
+                if i < 0:
+                    continue
+                x[i], y[i] = c * cell, (ny - 1 - r) * cell
+                zs = float(dem[r, c])
+                nbr = [float(dem[r + dr, c + dc]) for dr, dc in LATERAL_OFFSETS
+                       if 0 <= r + dr < ny and 0 <= c + dc < nx and valid[r + dr, c + dc]]
+                is_min = all(zs < v for v in nbr) if nbr else True
+                outward = edge[r, c] and (is_min or (nbr and zs <= min(nbr) + 0.5))
+                slp = float(np.float32(max(float(slope[r, c]), 0.001)))
+                if l == 0:
+                    z[i], size[i], surf[i] = float(np.float32(zs)), area, 1
+                    if outward:
+                        btype[i], bslope[i], barea[i] = capi.BND_RUNOFF, slp, cell
+                else:
+                    z[i] = float(np.float32(zs - centre[l - 1]))
+                    size[i] = area * thick[l - 1]
+                    soil_index[i - ns] = (int(zs) // 7 + l // 4) % n_soils
+                    last = (l + 1 >= nz) or index[l + 1, r, c] < 0
+                    if last:
+                        btype[i], barea[i] = capi.BND_FREE_DRAINAGE, area
+                    elif outward:
+                        btype[i], bslope[i], barea[i] = capi.BND_FREE_LATERAL_DRAINAGE, slp, float(np.float32(cell * thick[l - 1]))
+                if l > 0:
+                    ln.append(i); lt.append(index[l - 1, r, c]); ld.append(capi.LINK_UP); la.append(area)
+                if l + 1 < nz and index[l + 1, r, c] >= 0:
+                    ln.append(i); lt.append(index[l + 1, r, c]); ld.append(capi.LINK_DOWN); la.append(area)
+                lat = cell if l == 0 else float(np.float32(cell * thick[l - 1]))
+                for dr, dc in LATERAL_OFFSETS:
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < ny and 0 <= cc < nx and index[l, rr, cc] >= 0:
+                        ln.append(i); lt.append(index[l, rr, cc]); ld.append(capi.LINK_LATERAL); la.append(lat * 0.5)
+    soils = usda_soils()
+    soils = [soils[3], soils[4], soils[8]][:n_soils]       # silt loam, loam, clay loam
+    dtmin = min(6.0, cell / 20.0)
+    return Model(n=n, ns=ns, x=x, y=y, z=z, size=size, is_surface=surf, btype=btype, bslope=bslope, barea=barea,
+                 link_node=np.array(ln, np.uint32), link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8),
+                 link_area=np.array(la), soil_index=soil_index, soils=soils, psi0_soil=-3.0, lv_ratio=lv_ratio,
+                 numerics=(dtmin, 3600.0, 150, 10, 9, 2), cell_area=area, shape=(nx, ny, nz),
+                 meta=dict(kind="dem", layers=thick))

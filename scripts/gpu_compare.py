@@ -10,7 +10,7 @@ def compare(m, forcing, hours, max_steps=None):
     gpu, ora = capi.load_product(), capi.load_oracle()
     for sf in (gpu, ora):
         sf.lib.sf3d_reset_solver_state()
-        cm.build(sf, m, threads=(1 if m.n < 200000 else 64))
+        cm.build(sf, m, threads=(16 if m.n < 200000 else 32))
     for h in range(hours):
         out = []
         for sf in (gpu, ora):
@@ -35,6 +35,7 @@ hours = int(sys.argv[2]) if len(sys.argv) > 2 else None
 if which == 'c1': compare(cm.column_model(), 'R5', hours or 24)
 if which == 'c2f20': compare(cm.catchment_model(64, 64, 10), 'F20', hours or 6)
 if which == 'c2f60': compare(cm.catchment_model(64, 64, 10), 'F60', hours or 2, max_steps=500)
+if which == 'c2f60full': compare(cm.catchment_model(64, 64, 10), 'F60', hours or 3)
 if which == 'c3f20': compare(cm.catchment_model(256, 256, 15), 'F20', hours or 2)
 if which == 'c4f20': compare(cm.catchment_model(512, 512, 20), 'F20', hours or 1)
 if which == 'het': compare(cm.catchment_model(32, 32, 6, heterogeneous=True), 'F20', hours or 2, max_steps=500)

@@ -103,6 +103,17 @@ def ragged_geometric(sf, threads=1):
                   sinks_fn=_ragged_sinks, pre=_ragged_pre)
 
 
+def ravone_window(sf, threads=1):
+    """72x72 window of the Ravone DEM (DATA/DEM/DEM_Ravone.flt, rows 48-119, cols 444-515; 13 % NODATA,
+    127 m of relief), graph built like the caller does (catchment.dem_model): 14 soil layers to 0.95 m,
+    shallower soil on steep cells, float32-rounded geometry, real-terrain runoff with Courant
+    rejections.  Parameters of DATA/PROJECT/Ravone/SETTINGS/parameters.ini (ratio 4, accuracy 2)."""
+    from pathlib import Path
+    dem = np.load(Path(__file__).resolve().parent / "golden" / "ravone_dem_window_72x72.npy")
+    m = cm.dem_model(dem)
+    return _hours(sf, m, [(15.0, None, True), (15.0, 300, False), (0.0, 300, True)], threads)
+
+
 SCENARIOS = {
     "c1_column": c1_column,
     "c1_column_period": c1_column_period,
@@ -112,6 +123,7 @@ SCENARIOS = {
     "ragged_edge_cases": ragged_edge_cases,
     "ragged_arithmetic_vg": ragged_arithmetic_vg,
     "ragged_geometric": ragged_geometric,
+    "ravone_window": ravone_window,
 }
 
 
