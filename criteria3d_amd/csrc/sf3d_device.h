@@ -113,6 +113,11 @@ struct DistView {
     /* what I receive from peer p: node indices, count, offset in MY payload */
     const uint32_t* recvIdx[SF3D_MAX_RANKS]; uint32_t recvCount[SF3D_MAX_RANKS]; uint64_t recvOff[SF3D_MAX_RANKS];
     const uint8_t* owner;               /* [N] owning rank of each node (null when world == 1) */
+    /* the same send lists indexed by chunk, for kernels that put their boundary values themselves:
+     * entries [bndStart[q], bndStart[q+1]) belong to chunk q; each names the lane (node - 64 q), the
+     * destination rank and the position in that rank's send list */
+    const uint32_t* bndStart;           /* [nChunks + 1] */
+    const uint8_t* bndLane; const uint8_t* bndPeer; const uint32_t* bndSlot;
 };
 /* payload layout per (receiver, source p): [parity 0/1][field 0/1][count] doubles at offset off[p] */
 

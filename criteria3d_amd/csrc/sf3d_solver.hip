@@ -304,6 +304,60 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sync_kf(DevView v)
     dist_unpack(v, par, 1, v.flow);
 }
 
+/* ---- last-block hand-off inside a launch ---------------------------------------------------
+ * Every block calls this once, after a block-wide barrier that follows its last store.  Thread 0
+ * publishes the block's partial results write-through (sc1), drains them and arrives on a two-level
+ * agent-scope counter (16 shard counters on separate lines, then one top counter: a single counter
+ * serialises ~12 ns per block).  Returns true in every thread of the ONE block that arrived last;
+ * that block may then read all partials with sc1 loads (MI355X_MICROARCH.md "Valid forms": sc1 payload
+ * + drain + agent atomic add, consumer = the workgroup whose add came last). */
+__device__ __forceinline__ bool arrive_last(const DevView& v, double p0, double p1, bool twoValues)
+{
+    __shared__ int sLast;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&v.part0[blockIdx.x], p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (twoValues) __hip_atomic_store(&v.part1[blockIdx.x], p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int shard = blockIdx.x & 15u;
+        const unsigned int inShard = (gridDim.x + 15u - shard) >> 4;
+        const unsigned int shards = gridDim.x < 16u ? gridDim.x : 16u;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&v.arrive[16u * (shard + 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inShard - 1u) {
+            __hip_atomic_store(&v.arrive[16u * (shard + 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(&v.arrive[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u;
+            if (last) __hip_atomic_store(&v.arrive[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sLast = last;
+    }
+    __syncthreads();
+    return sLast != 0;
+}
+/* last block only: fixed-order sum of the published partials (same order as reduce_partials_sum) */
+__device__ __forceinline__ double sum_published(const double* p, uint32_t nb)
+{
+    double s = 0.;
+    for (uint32_t k = threadIdx.x; k < nb; k += SF3D_BLOCK) s += __hip_atomic_load(&p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return block_sum(s);
+}
+
+/* A wave puts the values its chunk owes to neighbouring ranks (multi-GPU, in-kernel halo put).
+ * All 64 lanes must call it; `val` is the lane's freshly computed value. */
+__device__ __forceinline__ void dist_put_chunk(const DevView& v, uint32_t q, uint32_t lane, uint32_t par, int field, double val)
+{
+    const DistView* d = v.dist;
+    const uint32_t b0 = d->bndStart[q], b1 = d->bndStart[q + 1];           /* wave-uniform */
+    for (uint32_t base = b0; base < b1; base += 64) {
+        const uint32_t t = base + lane;
+        const bool on = t < b1;
+        const double x = __shfl(val, on ? (int)d->bndLane[t] : 0, 64);
+        if (on) {
+            const uint32_t p = d->bndPeer[t];
+            double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * 2 + field) * d->sendCount[p] + d->bndSlot[t];
+            SYS_STORE(dst, x);
+        }
+    }
+}
+
 /* ======================================================================================= */
 /* control kernels (one thread / one block)                                                 */
 /* ======================================================================================= */
@@ -530,6 +584,7 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
 
 /* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
  * updateBoundaryWaterData (water.cpp:632-807) */
+template <int MODE>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -537,23 +592,37 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
     const uint32_t wrc = c->wrc;
+    const uint32_t par = c->epoch & 1u;
     const bool first = c->approx == 0;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (NOT_MINE(v, i)) continue;
-        const double H = Xc[i], Ho = Xh[i], z = v.z[i];
-        double K = 0.;
-        if (i >= v.ns) {
-            const SoilDev s = v.soils[v.cls[i]];
-            double Se, SeH;
-            if (first) { Se = node_se(s, H, z, wrc); SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se; }
-            else { Se = v.Se[i]; SeH = v.SeHold[i]; }
-            K = mualem_k(s, Se, wrc);
-            v.K[i] = K;
-            v.C[i] = v.size[i] * dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
+        const bool mine = !NOT_MINE(v, i);
+        double K = 0., fl = 0.;
+        if (mine) {
+            const double H = Xc[i], Ho = Xh[i], z = v.z[i];
+            if (i >= v.ns) {
+                const SoilDev s = v.soils[v.cls[i]];
+                double Se, SeH;
+                if (first) { Se = node_se(s, H, z, wrc); SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se; }
+                else { Se = v.Se[i]; SeH = v.SeHold[i]; }
+                K = mualem_k(s, Se, wrc);
+                v.K[i] = K;
+                v.C[i] = v.size[i] * dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
+            }
+            boundary_update(v, c, i, H, Ho, z, K);
+            if (MODE == 2) fl = v.flow[i];
         }
-        boundary_update(v, c, i, H, Ho, z, K);
+        if (MODE == 2) { dist_put_chunk(v, q, lane_, par, 0, K); dist_put_chunk(v, q, lane_, par, 1, fl); }
     }
+    if (MODE != 2) return;
+    /* multi GPU: barrier across ranks + halo of K / waterFlow before the assembly reads neighbours */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!arrive_last(v, 0., 0., false)) return;
+    double vals[3] = {0., 0., 0.};
+    if (!dist_allgather(v, v.ctrl, vals, 0)) return;
+    dist_unpack(v, par, 0, v.K);
+    dist_unpack(v, par, 1, v.flow);
 }
 
 /* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
@@ -763,81 +832,68 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView
 /* JacobiWaterCPU, water.cpp:565-601.
  * All coefficient loads, then all neighbour gathers, are issued before the ordered accumulation
  * so that ~30 independent loads per lane are in flight (HBM-bound kernel, 152 algorithmic B/node). */
-template <bool FUSED>
+/* MODE 0: partials only (a separate k_decide_sweep follows).  MODE 1 (single GPU): the block that
+ * arrives last also takes the convergence decision.  MODE 2 (multi GPU): each wave additionally puts
+ * the new iterate of its boundary nodes into the neighbours' windows, and the last block all-gathers
+ * the norm, copies the received halo and decides - one launch per sweep in every configuration. */
+template <int MODE>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_SWEEP) return;
+    const int nxt = free_buffer(c);
+    const uint32_t par = c->epoch & 1u;
     const double* __restrict__ xin = v.X[c->cur];
-    double* __restrict__ xout = v.X[free_buffer(c)];
+    double* __restrict__ xout = v.X[nxt];
     const sf3d_d2* __restrict__ A2 = v.A2;
     double nrm = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (NOT_MINE(v, i)) continue;
-        double a[SF3D_SLOTS], xj[SF3D_SLOTS];
-        uint32_t j[SF3D_SLOTS];
-        #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
-        const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) {
-            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];   /* 0 for a missing link: in range */
-            else j[s] = i + cd.delta[s];                                     /* offset 0 when the slot is empty */
+        const bool mine = !NOT_MINE(v, i);
+        double xn = 0.;
+        if (mine) {
+            double a[SF3D_SLOTS], xj[SF3D_SLOTS];
+            uint32_t j[SF3D_SLOTS];
+            #pragma unroll
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+            const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
+            #pragma unroll
+            for (int s = 0; s < SF3D_SLOTS; ++s) {
+                if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];   /* 0 for a missing link: in range */
+                else j[s] = i + cd.delta[s];                                     /* offset 0 when the slot is empty */
+            }
+            const double bi = v.b[i], zi = v.z[i], xi = xin[i];
+            #pragma unroll
+            for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
+            xn = bi;
+            constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+            #pragma unroll
+            for (int o = 0; o < SF3D_SLOTS; ++o) {
+                const uint32_t s = order[o];
+                if (a[s] != 0.) xn -= a[s] * xj[s];                              /* zero entries are not in the reference's row */
+            }
+            if (i < v.ns) xn = dmax(xn, zi);
+            double d = fabs(xn - xi);
+            const double psi = fabs(xn - zi);
+            if (psi > 1.) d *= (1. / psi);
+            nrm += d;
+            xout[i] = xn;
         }
-        const double bi = v.b[i], zi = v.z[i], xi = xin[i];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
-        double xn = bi;
-        constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-        #pragma unroll
-        for (int o = 0; o < SF3D_SLOTS; ++o) {
-            const uint32_t s = order[o];
-            if (a[s] != 0.) xn -= a[s] * xj[s];                              /* zero entries are not in the reference's row */
-        }
-        if (i < v.ns) xn = dmax(xn, zi);
-        double d = fabs(xn - xi);
-        const double psi = fabs(xn - zi);
-        if (psi > 1.) d *= (1. / psi);
-        nrm += d;
-        xout[i] = xn;
+        if (MODE == 2) dist_put_chunk(v, q, lane_, par, 0, xn);
     }
+    if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* every wave drains its puts before the barrier */
     const double bs = block_sum(nrm);
-    if (!FUSED) {
+    if (MODE == 0) {
         if (threadIdx.x == 0) v.part0[blockIdx.x] = bs;
         return;
     }
-    /* Single GPU: the block that arrives last reduces the partials (fixed order) and takes the
-     * convergence decision, saving one launch per sweep.  Hand-off per MI355X_MICROARCH.md
-     * "Valid forms": one lane per block stores its partial write-through (sc1), drains it, then
-     * adds to an agent-scope counter; the block whose add returns nb-1 reads the partials with sc1
-     * loads.  Nothing else crosses blocks inside the launch (xout is read by the NEXT kernel). */
-    __shared__ int sLast;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&v.part0[blockIdx.x], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        /* two-level arrival (16 shard counters on separate lines, then one top counter): a single
-         * counter serialises ~12 ns per block, 25 us for 2048 blocks */
-        const unsigned int shard = blockIdx.x & 15u;
-        const unsigned int inShard = (gridDim.x + 15u - shard) >> 4;
-        const unsigned int shards = gridDim.x < 16u ? gridDim.x : 16u;
-        int last = 0;
-        if (__hip_atomic_fetch_add(&v.arrive[16u * (shard + 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == inShard - 1u) {
-            __hip_atomic_store(&v.arrive[16u * (shard + 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = __hip_atomic_fetch_add(&v.arrive[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u;
-        }
-        sLast = last;
+    if (!arrive_last(v, bs, 0., false)) return;
+    double vals[3] = {sum_published(v.part0, gridDim.x), 0., 0.};
+    if (MODE == 2) {
+        if (!dist_allgather(v, v.ctrl, vals, 0)) return;
+        dist_unpack(v, par, 0, v.X[nxt]);                                 /* neighbours' new iterate on my halo */
     }
-    __syncthreads();
-    if (!sLast) return;
-    double s = 0.;
-    for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK)
-        s += __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double total = block_sum(s);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(v.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sweep_decision(v.ctrl, free_buffer(c), total / v.N);
-    }
+    if (threadIdx.x == 0) sweep_decision(v.ctrl, nxt, vals[0] / v.N);
 }
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
@@ -1306,6 +1362,30 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                 if (d.recvCount[pr]) HIP_TRY(hipMemcpy(ri, I.part.recv[pr].data(), (size_t)d.recvCount[pr] * 4, hipMemcpyHostToDevice));
                 d.sendIdx[pr] = si; d.recvIdx[pr] = ri;
             }
+            {   /* the send lists regrouped by chunk for the in-kernel puts */
+                struct Ent { uint32_t node; uint8_t peer; uint32_t slot; };
+                std::vector<Ent> ents;
+                for (int pr = 0; pr < world_; ++pr)
+                    for (uint32_t k = 0; k < I.part.send[pr].size(); ++k) ents.push_back({I.part.send[pr][k], (uint8_t)pr, k});
+                std::sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.node != b.node ? a.node < b.node : a.peer < b.peer; });
+                std::vector<uint32_t> bstart(nChunks + 1, 0), bslot(ents.size());
+                std::vector<uint8_t> blane(ents.size()), bpeer(ents.size());
+                for (size_t k = 0; k < ents.size(); ++k) {
+                    bstart[ents[k].node / SF3D_CHUNK + 1]++;
+                    blane[k] = (uint8_t)(ents[k].node % SF3D_CHUNK); bpeer[k] = ents[k].peer; bslot[k] = ents[k].slot;
+                }
+                for (uint32_t q = 0; q < nChunks; ++q) bstart[q + 1] += bstart[q];
+                uint32_t *dbs, *dsl; uint8_t *dla, *dpe;
+                HIP_TRY(dev_alloc(I.allocs, dbs, bstart.size())); HIP_TRY(dev_alloc(I.allocs, dsl, bslot.size()));
+                HIP_TRY(dev_alloc(I.allocs, dla, blane.size())); HIP_TRY(dev_alloc(I.allocs, dpe, bpeer.size()));
+                HIP_TRY(hipMemcpy(dbs, bstart.data(), bstart.size() * 4, hipMemcpyHostToDevice));
+                if (!ents.empty()) {
+                    HIP_TRY(hipMemcpy(dsl, bslot.data(), bslot.size() * 4, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(dla, blane.data(), blane.size(), hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(dpe, bpeer.data(), bpeer.size(), hipMemcpyHostToDevice));
+                }
+                d.bndStart = dbs; d.bndSlot = dsl; d.bndLane = dla; d.bndPeer = dpe;
+            }
             I.windowBytes = sizeof(DistWindow) + off * sizeof(double);
             void* w = nullptr;
             HIP_TRY(hipExtMallocWithFlags(&w, I.windowBytes, hipDeviceMallocFinegrained));
@@ -1513,6 +1593,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool multi = world_ > 1;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
+    const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
@@ -1535,8 +1616,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* one approximation's worth of guarded kernels */
     auto enqueue_batch = [&](bool withHead, bool withTail) {
         if (withHead) {
-            timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props, grid, block, 0, st, v); });
-            if (multi) {
+            if (multi && fusedMulti) timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props<2>, grid, block, 0, st, v); });
+            else timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props<0>, grid, block, 0, st, v); });
+            if (multi && !fusedMulti) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
@@ -1547,8 +1629,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
         for (uint32_t k = 0; k < chunk; ++k) {
-            if (fused) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<true>, grid, block, 0, st, v); }); continue; }
-            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<false>, grid, block, 0, st, v); });
+            if (fused) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<1>, grid, block, 0, st, v); }); continue; }
+            if (fusedMulti) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<2>, grid, block, 0, st, v); }); continue; }
+            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<0>, grid, block, 0, st, v); });
             if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }
