@@ -2,16 +2,24 @@
 (kernel trace) and HBM traffic per launch from the PMC passes, corrected as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B
 request: x2; WRITE_SIZE exact; both in KiB)."""
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
+
+def base(name):
+    """k_sweep<1>(DevView) / void k_sweep<1>(DevView) -> k_sweep"""
+    name = name.strip()
+    if name.startswith("void "):
+        name = name[5:]
+    return re.split(r"[<(]", name)[0]
+
 out = sys.argv[1]
 res = {}
 f = glob.glob(f"{out}/trace/*/*kernel_trace.csv")
 if f:
     dur = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
-        dur[row["Kernel_Name"].split("(")[0]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        dur[base(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for k, v in dur.items():
-        active = [x for x in v if x > 0.25 * max(v)] if k in ("k_sweep", "k_props", "k_assemble_soil", "k_assemble_surface", "k_post", "k_accept", "k_restore") else v
+        active = [x for x in v if x > 0.25 * max(v)] if k in ("k_sweep", "k_props", "k_assemble", "k_post", "k_accept", "k_restore") else v
         res.setdefault(k, {})["launches"] = len(v)
         res[k]["active_launches"] = len(active)
         res[k]["avg_active_us"] = sum(active) / max(len(active), 1) / 1e3
@@ -21,7 +29,7 @@ for cnt, key, corr in (("FETCH_SIZE", "hbm_read_MB", 2.0), ("WRITE_SIZE", "hbm_w
     if not f: continue
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
-        agg[row["Kernel_Name"].split("(")[0]].append(float(row["Counter_Value"]))
+        agg[base(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     for k, v in agg.items():
         big = [x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v
         res.setdefault(k, {})[key] = corr * (sum(big) / max(len(big), 1)) * 1024 / 1e6
