@@ -32,7 +32,8 @@ sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
 
-WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20)}
+WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
+             "C5S": (519, 1208, 15)}      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
 ALGO_BYTES = {"k_sweep": 152, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
@@ -170,7 +171,7 @@ def main():
 
     nx, ny, nz = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    model = cm.catchment_model(nx, ny, nz)
+    model = cm.dem_model_fast(cm.synthetic_dem(ny, nx)) if args.workload == "C5S" else cm.catchment_model(nx, ny, nz)
     log(f"[bench] rank {rank}: {args.workload} model arrays in {time.perf_counter() - t0:.1f}s ({model.n} nodes)")
 
     def fresh():
@@ -256,7 +257,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} tilted-plane catchment (SURVEY.md 8d), forcing {args.forcing}, "
+        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ("synthetic Ravone-like DEM (irregular)" if args.workload == "C5S" else "tilted-plane catchment (SURVEY.md 8d)") + f", forcing {args.forcing}, "
                                f"{args.steps} simulated hours from the initial state",
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},

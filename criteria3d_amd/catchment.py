@@ -432,3 +432,99 @@ def dem_model(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, depth
                  link_area=np.array(la), soil_index=soil_index, soils=soils, psi0_soil=-3.0, lv_ratio=lv_ratio,
                  numerics=(dtmin, 3600.0, 150, 10, 9, 2), cell_area=area, shape=(nx, ny, nz),
                  meta=dict(kind="dem", layers=thick))
+
+
+def dem_model_fast(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, depth: float = 0.95,
+                   lv_ratio: float = 4.0, n_soils: int = 3) -> Model:
+    """Vectorised twin of dem_model (same rules, same node/link order, identical arrays - checked by
+    tests/test_abi.py on the Ravone window) for catchments of millions of nodes."""
+    dem = np.asarray(dem, np.float32)
+    ny, nx = dem.shape
+    valid = dem != nodata
+    thick = np.array(dem_layer_thicknesses(depth))
+    nz = len(thick) + 1
+    centre = np.cumsum(thick) - 0.5 * thick
+    bottom = np.cumsum(thick)
+    gy, gx = np.gradient(np.where(valid, dem, np.nan).astype(np.float64), cell)
+    slope = np.sqrt(np.nan_to_num(gx) ** 2 + np.nan_to_num(gy) ** 2)
+    soil_depth = np.clip(depth * (1.0 - 0.8 * np.clip(slope, 0, 1)), 0.25, depth)
+    exists = np.zeros((nz, ny, nx), bool)
+    exists[0] = valid
+    for l in range(1, nz):
+        exists[l] = valid & ((bottom[l - 1] <= soil_depth + 1e-9) | (l == 1))
+    index = np.where(exists, np.cumsum(exists.ravel()).reshape(exists.shape) - 1, -1)
+    n, ns, area = int(exists.sum()), int(valid.sum()), cell * cell
+    L, R, C = np.nonzero(exists)                                  # layer-major, row-major order = node order
+    zs64 = dem.astype(np.float64)
+
+    pad = np.pad(valid, 1, constant_values=False)
+    zpad = np.pad(np.where(valid, zs64, np.inf), 1, constant_values=np.inf)
+    edge = np.zeros((ny, nx), bool)
+    nmin = np.full((ny, nx), np.inf)
+    for dr, dc in LATERAL_OFFSETS:
+        nb_valid = pad[1 + dr:1 + dr + ny, 1 + dc:1 + dc + nx]
+        edge |= valid & ~nb_valid
+        nmin = np.minimum(nmin, zpad[1 + dr:1 + dr + ny, 1 + dc:1 + dc + nx])
+    has_nbr = np.isfinite(nmin)
+    is_min = np.where(has_nbr, zs64 < nmin, True)
+    outward2d = edge & (is_min | (has_nbr & (zs64 <= nmin + 0.5)))
+    slp2d = np.maximum(slope, 0.001).astype(np.float32).astype(np.float64)
+
+    zsn, outward = zs64[R, C], outward2d[R, C]
+    soil = L > 0
+    lc = np.maximum(L - 1, 0)
+    x = C * cell
+    y = (ny - 1 - R) * cell
+    z = np.where(soil, (zsn - centre[lc]).astype(np.float32).astype(np.float64), zsn)
+    size = np.where(soil, area * thick[lc], area)
+    surf = (~soil).astype(np.uint8)
+    below = np.zeros_like(exists)
+    below[:-1] = exists[1:]
+    last = soil & ~below[L, R, C]
+    btype = np.zeros(n, np.uint8); bslope = np.zeros(n); barea = np.zeros(n)
+    m = ~soil & outward
+    btype[m] = capi.BND_RUNOFF; bslope[m] = slp2d[R, C][m]; barea[m] = cell
+    m = soil & ~last & outward
+    btype[m] = capi.BND_FREE_LATERAL_DRAINAGE; bslope[m] = slp2d[R, C][m]
+    barea[m] = (cell * thick[lc]).astype(np.float32).astype(np.float64)[m]
+    btype[last] = capi.BND_FREE_DRAINAGE; bslope[last] = 0.0; barea[last] = area
+    soil_index = ((zsn[soil].astype(np.int64) // 7 + L[soil] // 4) % n_soils).astype(np.uint16)
+
+    ipad = np.pad(index, ((1, 1), (1, 1), (1, 1)), constant_values=-1)
+    cand_to = np.full((n, 10), -1, np.int64)
+    cand_dir = np.zeros((n, 10), np.uint8)
+    cand_area = np.zeros((n, 10))
+    cand_to[:, 0] = ipad[L, R + 1, C + 1]; cand_dir[:, 0] = capi.LINK_UP; cand_area[:, 0] = area
+    cand_to[:, 1] = ipad[L + 2, R + 1, C + 1]; cand_dir[:, 1] = capi.LINK_DOWN; cand_area[:, 1] = area
+    lat = np.where(soil, (cell * thick[lc]).astype(np.float32).astype(np.float64), cell) * 0.5
+    for k, (dr, dc) in enumerate(LATERAL_OFFSETS):
+        cand_to[:, 2 + k] = ipad[L + 1, R + 1 + dr, C + 1 + dc]
+        cand_dir[:, 2 + k] = capi.LINK_LATERAL
+        cand_area[:, 2 + k] = lat
+    mask = cand_to >= 0
+    idx = np.arange(n, dtype=np.int64)
+    soils = usda_soils()
+    soils = [soils[3], soils[4], soils[8]][:n_soils]
+    return Model(n=n, ns=ns, x=x.astype(float), y=y.astype(float), z=z, size=size, is_surface=surf, btype=btype, bslope=bslope,
+                 barea=barea, link_node=np.broadcast_to(idx[:, None], (n, 10))[mask].astype(np.uint32),
+                 link_to=cand_to[mask].astype(np.uint32), link_dir=cand_dir[mask], link_area=cand_area[mask],
+                 soil_index=soil_index, soils=soils, psi0_soil=-3.0, lv_ratio=lv_ratio,
+                 numerics=(min(6.0, cell / 20.0), 3600.0, 150, 10, 9, 2), cell_area=area, shape=(nx, ny, nz),
+                 meta=dict(kind="dem", layers=list(thick)))
+
+
+def synthetic_dem(ny: int = 1208, nx: int = 519, seed: int = 2021, nodata: float = -9999.0) -> np.ndarray:
+    """Deterministic fractal hill-slope terrain with an irregular catchment outline, shaped like the
+    Ravone DEM (DATA/DEM/DEM_Ravone.hdr: 519 x 1208 cells of 4 m, 70-358 m a.s.l., two thirds valid)."""
+    rng = np.random.RandomState(seed)
+    ky = np.fft.fftfreq(ny)[:, None]; kx = np.fft.fftfreq(nx)[None, :]
+    k = np.sqrt(kx * kx + ky * ky); k[0, 0] = 1.0
+    spec = (rng.normal(size=(ny, nx)) + 1j * rng.normal(size=(ny, nx))) / k ** 2.1
+    rough = np.real(np.fft.ifft2(spec)); rough = (rough - rough.min()) / (rough.max() - rough.min())
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    axis = nx * (0.5 + 0.18 * np.sin(yy / ny * 5.0) + 0.07 * np.sin(yy / ny * 17.0))      # meandering valley axis
+    dist = np.abs(xx - axis) / nx
+    elev = 70.0 + 200.0 * (1.0 - yy / ny) * 0.6 + 380.0 * dist + 60.0 * rough
+    half_width = 0.30 + 0.10 * np.sin(yy / ny * 9.0) + 0.05 * (rough - 0.5)
+    dem = np.where(dist < half_width, elev, nodata).astype(np.float32)
+    return dem

@@ -38,4 +38,5 @@ if which == 'c2f60': compare(cm.catchment_model(64, 64, 10), 'F60', hours or 2, 
 if which == 'c2f60full': compare(cm.catchment_model(64, 64, 10), 'F60', hours or 3)
 if which == 'c3f20': compare(cm.catchment_model(256, 256, 15), 'F20', hours or 2)
 if which == 'c4f20': compare(cm.catchment_model(512, 512, 20), 'F20', hours or 1)
+if which == 'c5s': compare(cm.dem_model_fast(cm.synthetic_dem()), 'F20', 1, max_steps=int(sys.argv[2]) if len(sys.argv) > 2 else 40)
 if which == 'het': compare(cm.catchment_model(32, 32, 6, heterogeneous=True), 'F20', hours or 2, max_steps=500)

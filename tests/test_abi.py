@@ -176,3 +176,14 @@ def test_v1_alias_exports_the_retired_names():
                  "_ZN12soilFluxes3D2v111computeStepEd", "_ZN12soilFluxes3D2v123getBoundaryWaterSumFlowEi"):
         assert want in syms, want
     assert len([s for s in syms if s.startswith("_ZN12soilFluxes3D2v1")]) == 65
+
+
+def test_vectorised_dem_builder_equals_the_readable_one():
+    from criteria3d_amd import catchment as cm
+    dem = np.load(ROOT / "tests" / "golden" / "ravone_dem_window_72x72.npy")
+    a, b = cm.dem_model(dem), cm.dem_model_fast(dem)
+    assert (a.n, a.ns) == (b.n, b.ns)
+    for f in ("x", "y", "z", "size", "is_surface", "btype", "bslope", "barea", "link_node", "link_to", "link_dir",
+              "link_area", "soil_index"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert len(cm.dem_layer_thicknesses(0.95)) == 14            # 14 layers for 0.95 m
