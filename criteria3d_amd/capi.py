@@ -127,6 +127,7 @@ SIGNATURES = {
     "sf3d_get_nodes_boundary_water_flow": (u8, [u32, u32, pd]),
     "sf3d_get_counters": (u8, [p64]),
     "sf3d_get_time_step": (f64, []),
+    "sf3d_set_time_step": (u8, [f64]),
     "sf3d_reset_solver_state": (u8, []),
     "sf3d_set_surface_nodes_number": (u8, [u32]),
     "sf3d_set_device": (u8, [i32]),

@@ -537,6 +537,14 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
     return SF3D_OK;
 }
 double sf3d_get_time_step(void) { return P.dtCurr; }
+sf3d_error_t sf3d_set_time_step(double dt)
+{
+    if (!M.solverReady) return SF3D_MEMORY_ERROR;
+    if (!(dt > 0.)) return SF3D_PARAMETER_ERROR;
+    P.dtCurr = std::min(std::max(dt, P.dtMin), P.dtMax);
+    M.ctrlDirty = true;
+    return SF3D_OK;
+}
 sf3d_error_t sf3d_reset_solver_state(void) { P = ParamsHost(); M.ctrlDirty = true; return SF3D_OK; }
 sf3d_error_t sf3d_set_surface_nodes_number(uint32_t ns)
 {

@@ -302,6 +302,11 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8]);
 
 /* current adaptive time step deltaTcurr [s] (Solver::getTimeStep, solver.h:36) */
 double sf3d_get_time_step(void);
+/* Restore the adaptive time step of a checkpointed run (the reference keeps deltaTcurr only in
+ * memory - SURVEY.md 5 "deltaTcurr is not checkpointed" - although Solver::setTimeStep exists,
+ * solver.h:77-86).  Together with sf3d_get_time_step and the state setters/getters this resumes a
+ * simulation on the exact trajectory.  The value is clamped to [deltaTmin, deltaTmax]. */
+sf3d_error_t sf3d_set_time_step(double deltaT);
 /* Put every persistent solver parameter back to its fresh-process default (SolverParameters,
  * types.h:291-315: deltaTcurr = NODATA -> deltaTmax at the next initialize, deltaTmax = 600, ...).
  * The reference keeps them across re-initialisations (global CPUSolverObject, SURVEY.md 8a

@@ -152,6 +152,7 @@ sf3d_error_t sf3d_get_counters(uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 /* Solver::getTimeStep is public on the reference's global `solver` object but that object is
  * not part of the public header; not available here */
 double sf3d_get_time_step(void) { return SF3D_VAL_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_set_time_step(double) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_reset_solver_state(void) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_set_surface_nodes_number(uint32_t) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_set_device(int) { return SF3D_MISSING_DATA_ERROR; }
