@@ -185,8 +185,9 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
                                                  s["organic_matter"], s["clay"]), "set_soil_properties")
     sf.set_nodes_bulk(0, m.x, m.y, m.z, m.size, m.is_surface, m.btype, m.bslope, m.barea)
     sf.set_links_bulk(m.link_node, m.link_to, m.link_dir, m.link_area)
-    sf.set_surface_bulk(0, np.zeros(m.ns, np.uint16))
-    sf.set_pond_bulk(0, np.full(m.ns, m.pond))
+    if m.ns > 0:
+        sf.set_surface_bulk(0, np.zeros(m.ns, np.uint16))
+        sf.set_pond_bulk(0, np.full(m.ns, m.pond))
     if m.n > m.ns:
         sf.set_soil_bulk(m.ns, m.soil_index, np.zeros(m.n - m.ns, np.uint16))
     sf.check(sf.lib.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, m.lv_ratio),
@@ -528,3 +529,33 @@ def synthetic_dem(ny: int = 1208, nx: int = 519, seed: int = 2021, nodata: float
     half_width = 0.30 + 0.10 * np.sin(yy / ny * 9.0) + 0.05 * (rough - 0.5)
     dem = np.where(dist < half_width, elev, nodata).astype(np.float32)
     return dem
+
+
+def surface_only_model(nx: int = 12, ny: int = 10, cell: float = 5.0) -> Model:
+    """Edge case: a sheet of surface nodes only (no soil, no vertical links): pure St-Venant runoff."""
+    full = catchment_model(nx, ny, 1, cell=cell)
+    full.psi0_surface = 0.003           # 3 mm of water everywhere to start with
+    full.meta = dict(kind="surface_only")
+    return full
+
+
+def soil_only_column(n_nodes: int = 40, dz: float = 0.05) -> Model:
+    """Edge case: nrSurfaceNodes = 0 - a soil column with a prescribed-potential top node and free
+    drainage at the bottom (no surface node at all)."""
+    n = n_nodes
+    i = np.arange(n)
+    z = -(dz * (i + 0.5))
+    btype = np.zeros(n, np.uint8); barea = np.zeros(n)
+    btype[n - 1] = capi.BND_FREE_DRAINAGE; barea[n - 1] = 1.0
+    btype[0] = capi.BND_PRESCRIBED; barea[0] = 1.0
+    ln, lt, ld = [], [], []
+    for k in range(n):
+        if k > 0:
+            ln.append(k); lt.append(k - 1); ld.append(capi.LINK_UP)
+        if k < n - 1:
+            ln.append(k); lt.append(k + 1); ld.append(capi.LINK_DOWN)
+    return Model(n=n, ns=0, x=np.zeros(n), y=np.zeros(n), z=z, size=np.full(n, dz), is_surface=np.zeros(n, np.uint8),
+                 btype=btype, bslope=np.zeros(n), barea=barea, link_node=np.array(ln, np.uint32),
+                 link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8), link_area=np.ones(len(ln)),
+                 soil_index=np.zeros(n, np.uint16), soils=[LOAM], psi0_soil=-2.5, numerics=(1.0, 3600.0, 150, 10, 10, 3),
+                 cell_area=1.0, shape=(1, 1, n), meta=dict(kind="soil_only", prescribed_node=0, prescribed_H=-0.2))

@@ -114,6 +114,18 @@ def ravone_window(sf, threads=1):
     return _hours(sf, m, [(15.0, None, True), (15.0, 300, False), (0.0, 300, True)], threads)
 
 
+def surface_only(sf, threads=1):
+    """no soil at all: 3 mm of ponded water runs off a tilted sheet, then 10 mm of rain"""
+    m = cm.surface_only_model()
+    return _hours(sf, m, [(0.0, None, True), (10.0, None, True)], threads)
+
+
+def soil_only(sf, threads=1):
+    """nrSurfaceNodes = 0: soil column wetted from a prescribed-potential top node"""
+    m = cm.soil_only_column()
+    return _hours(sf, m, [(0.0, None, True), (0.0, None, True)], threads, pre=_ragged_pre)
+
+
 SCENARIOS = {
     "c1_column": c1_column,
     "c1_column_period": c1_column_period,
@@ -124,6 +136,8 @@ SCENARIOS = {
     "ragged_arithmetic_vg": ragged_arithmetic_vg,
     "ragged_geometric": ragged_geometric,
     "ravone_window": ravone_window,
+    "surface_only": surface_only,
+    "soil_only": soil_only,
 }
 
 
