@@ -1534,7 +1534,7 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
 sf3d_error_t DeviceSolver::dist_prepare(int rank, int world)
 {
     if (world < 1 || world > SF3D_MAX_RANKS || rank < 0 || rank >= world) { snprintf(err_, sizeof(err_), "dist_prepare: bad rank/world %d/%d", rank, world); return SF3D_PARAMETER_ERROR; }
-    if (built_) { snprintf(err_, sizeof(err_), "dist_prepare must precede the first device build (call it before sf3d_initialize)"); return SF3D_SOLVER_ERROR; }
+    if (built_) release();            /* a model built for another (or the same) partition: drop it, sf3d_initialize follows */
     world_ = world; rank_ = rank; connected_ = false;
     return SF3D_OK;
 }

@@ -29,6 +29,10 @@ elif case == "ragged":
     m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
 else:
     raise SystemExit("unknown case")
+# a throw-away model first: re-initialisation must drop the windows, re-export and re-connect
+sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+cm.build(sf, m, threads=1, dist=(rank, world, allgather))
+cm.run_hour(sf, m, 5.0, max_steps=2)
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 cm.build(sf, m, threads=1, dist=(rank, world, allgather))
 owner = sf.owner_map(world, m.n)
