@@ -130,6 +130,9 @@ struct DevView {
     /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
+    uint32_t ntStream;                  /* 1: streamed-once arrays (coefficients, link geometry, flow sums) bypass the caches
+                                           (they would evict x, b, z from the 256 MiB Infinity Cache); 0 when the whole
+                                           working set of a rank fits the cache (small grids, 8-way sharding) */
     const DistView* dist;               /* device copy; null when world == 1 */
     int32_t world, rank;
     const uint8_t* owner;               /* = dist->owner, null when world == 1 */

@@ -38,6 +38,35 @@
 /* device helpers                                                                           */
 /* ======================================================================================= */
 
+/* Streaming accesses that do not allocate in the caches: the coefficient slabs (80 B/node, read exactly
+ * once per sweep by exactly one wave), the static link geometry and the per-link flow sums would
+ * otherwise evict x, b and z from L2 / the 256 MiB Infinity Cache between two sweeps.  `NT is a kernel
+ * template parameter chosen per launch from DevView::ntStream (a run-time select of the two forms is
+ * merged by the compiler into one plain load): off when a rank's whole working set fits the Infinity Cache. */
+typedef double sf3d_v2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ sf3d_d2 load_coeff(const sf3d_d2* p)
+{
+    sf3d_v2 t;
+    if (NT) t = __builtin_nontemporal_load(reinterpret_cast<const sf3d_v2*>(p));
+    else t = *reinterpret_cast<const sf3d_v2*>(p);
+    sf3d_d2 r; r.x = t.x; r.y = t.y; return r;
+}
+template <bool NT> __device__ __forceinline__ void store_coeff(sf3d_d2* p, double x, double y)
+{
+    sf3d_v2 t; t.x = x; t.y = y;
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<sf3d_v2*>(p));
+    else *reinterpret_cast<sf3d_v2*>(p) = t;
+}
+template <bool NT, class T> __device__ __forceinline__ T load_stream(const T* p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+template <bool NT, class T> __device__ __forceinline__ void store_stream(T* p, T x)
+{
+    if (NT) __builtin_nontemporal_store(x, p); else *p = x;
+}
+
 /* std::max / std::min semantics (NaN handling included) */
 __device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
@@ -708,6 +737,7 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
 /* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
  * computeDiagonalElement (:335-345) + preconditioningMatrix (:284-305), in two kernels like the
  * reference's two loops (surface rows, Courant check, soil rows - cpusolver.cpp:412-429). */
+template <bool NT>
 __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&k)[SF3D_SLOTS],
                                           double sum, double Hoi, double dt)
 {
@@ -717,14 +747,14 @@ __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd,
     #pragma unroll
     for (int p = 0; p < SF3D_SLOTS / 2; ++p)
         if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) {
-            sf3d_d2 a; a.x = (k[2 * p] * -1.) * inv; a.y = (k[2 * p + 1] * -1.) * inv;
-            v.A2[(size_t)p * v.N + i] = a;
+            store_coeff<NT>(&v.A2[(size_t)p * v.N + i], (k[2 * p] * -1.) * inv, (k[2 * p + 1] * -1.) * inv);
         }
     v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
 }
 
 /* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
  * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
+template <bool NT>
 __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
@@ -757,7 +787,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
             k[s] = ks;
             sum += ks;
         }
-        store_row(v, cd, i, k, sum, Hoi, dt);
+        store_row<NT>(v, cd, i, k, sum, Hoi, dt);
     }
     return block_max(courant);
 }
@@ -768,6 +798,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
+template <bool NT>
 __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
@@ -796,10 +827,10 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 kd[t] = LK_NONE; j[t] = i; area[t] = 0.; dist[t] = 1.;
                 if (cd.kind[s] != CK_NONE) {
                     const size_t e = (size_t)s * v.N + i;
-                    if (cd.kind[s] == CK_MIXED) { kd[t] = v.lkind[e]; j[t] = v.lto[e]; }
+                    if (cd.kind[s] == CK_MIXED) { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
                     else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
-                    area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : v.larea[e];
-                    dist[t] = v.ldist[e];
+                    area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : load_stream<NT>(&v.larea[e]);
+                    dist[t] = load_stream<NT>(&v.ldist[e]);
                 }
             }
             #pragma unroll
@@ -820,20 +851,20 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 sum += ks;
             }
         }
-        store_row(v, cd, i, k, sum, Hoi, dt);
+        store_row<NT>(v, cd, i, k, sum, Hoi, dt);
     }
 }
 
 /* one launch: blocks [0, nbSurf) assemble the surface rows (and reduce the Courant maximum),
  * blocks [nbSurf, nbSurf + nbSoil) the soil rows.  FUSED: the block that arrives last takes the
  * Courant decision (checkCourant) instead of a separate one-block kernel. */
-template <bool FUSED>
+template <bool FUSED, bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
     double bm = 0.;
-    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows(v, blockIdx.x, v.nbSurf);
-    else assemble_soil_rows(v, blockIdx.x - v.nbSurf, v.nbSoil);
+    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT>(v, blockIdx.x, v.nbSurf);
+    else assemble_soil_rows<NT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
     if (!FUSED) {
         if (threadIdx.x == 0 && blockIdx.x < v.nbSurf) v.part0[blockIdx.x] = bm;
         return;
@@ -855,7 +886,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView
  * arrives last also takes the convergence decision.  MODE 2 (multi GPU): each wave additionally puts
  * the new iterate of its boundary nodes into the neighbours' windows, and the last block all-gathers
  * the norm, copies the received halo and decides - one launch per sweep in every configuration. */
-template <int MODE>
+template <int MODE, bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -874,11 +905,11 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
             double a[SF3D_SLOTS], xj[SF3D_SLOTS];
             uint32_t j[SF3D_SLOTS];
             #pragma unroll
-            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }
             const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
             #pragma unroll
             for (int s = 0; s < SF3D_SLOTS; ++s) {
-                if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];   /* 0 for a missing link: in range */
+                if (cd.kind[s] == CK_MIXED) j[s] = load_stream<NT>(&v.lto[(size_t)s * v.N + i]);   /* 0 for a missing link: in range */
                 else j[s] = i + cd.delta[s];                                     /* offset 0 when the slot is empty */
             }
             const double bi = v.b[i], zi = v.z[i], xi = xin[i];
@@ -992,6 +1023,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
 
 /* acceptStep flow sums, water.cpp:240-250 + updateLinkFlux :269-277 (stored, row-normalised
  * coefficient as in the reference; a zero coefficient adds exactly 0) */
+template <bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -1005,7 +1037,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
         double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
         uint32_t j[SF3D_SLOTS];
         #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }   /* non-zero only where a link exists */
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }   /* non-zero only where a link exists */
         const ChunkDesc cd = v.cdesc[q];
         #pragma unroll
         for (int s = 0; s < SF3D_SLOTS; ++s) {
@@ -1014,10 +1046,10 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
         }
         const double Hi = X[i];
         #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? v.lflowSum[(size_t)s * v.N + i] : 0.; }
+        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? load_stream<NT>(&v.lflowSum[(size_t)s * v.N + i]) : 0.; }
         #pragma unroll
         for (int s = 0; s < SF3D_SLOTS; ++s)
-            if (a[s] != 0.) v.lflowSum[(size_t)s * v.N + i] = f[s] + a[s] * (Hi - xj[s]) * dt;
+            if (a[s] != 0.) store_stream<NT>(&v.lflowSum[(size_t)s * v.N + i], f[s] + a[s] * (Hi - xj[s]) * dt);
         if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
     }
 }
@@ -1376,6 +1408,13 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         if (!listSurf.empty()) HIP_TRY(hipMemcpy(dlist, listSurf.data(), listSurf.size() * 4, hipMemcpyHostToDevice));
         v.chunkList = dlist;
         v.owner = nullptr; v.dist = nullptr;
+        {   /* bytes one rank touches per sweep: 152 B per owned node.  Below the 256 MiB Infinity Cache the whole
+             * sweep working set stays cached between sweeps and bypassing costs ~8 % (measured at 0.98 M nodes);
+             * above it the coefficient stream would thrash x, b, z: bypass gains ~13 % at 5.2 M nodes */
+            const char* e = getenv("SF3D_NT_STREAM");
+            const double sweepBytes = 152.0 * (double)v.nList * SF3D_CHUNK;
+            v.ntStream = e ? (e[0] != '0') : (sweepBytes > 256.0 * 1024 * 1024);
+        }
         if (world_ > 1) {
             uint8_t* downer; HIP_TRY(dev_alloc(I.allocs, downer, N));
             HIP_TRY(hipMemcpy(downer, I.part.owner.data(), N, hipMemcpyHostToDevice));
@@ -1661,9 +1700,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
-            if (I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL(k_assemble<true>, dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
-                timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL(k_assemble<false>, dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
@@ -1671,9 +1710,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
         for (uint32_t k = 0; k < chunk; ++k) {
-            if (fused) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<1>, grid, block, 0, st, v); }); continue; }
-            if (fusedMulti) { timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<2>, grid, block, 0, st, v); }); continue; }
-            timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_sweep<0>, grid, block, 0, st, v); });
+            if (fused) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<1, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<1, false>), grid, block, 0, st, v); }); continue; }
+            if (fusedMulti) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<2, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<2, false>), grid, block, 0, st, v); }); continue; }
+            timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<0, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<0, false>), grid, block, 0, st, v); });
             if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }
@@ -1688,7 +1727,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore<false>, grid, block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
             }
-            timed(KID_ACCEPT, [&] { hipLaunchKernelGGL(k_accept, grid, block, 0, st, v); });
+            timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, grid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, grid, block, 0, st, v); });
         }
     };
 
