@@ -13,6 +13,7 @@ def base(name):
 
 out = sys.argv[1]
 res = {}
+pmc = {}
 f = glob.glob(f"{out}/trace/*/*kernel_trace.csv")
 if f:
     dur = collections.defaultdict(list)
@@ -30,6 +31,8 @@ for cnt, key, corr in (("FETCH_SIZE", "hbm_read_MB", 2.0), ("WRITE_SIZE", "hbm_w
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f[0])):
         agg[base(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    pmc[cnt] = {k: {"dispatches": len(v), "max_KiB": max(v), "mean_of_active_KiB": (lambda b: sum(b) / max(len(b), 1))([x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v)}
+                for k, v in agg.items()}
     for k, v in agg.items():
         big = [x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v
         res.setdefault(k, {})[key] = corr * (sum(big) / max(len(big), 1)) * 1024 / 1e6
@@ -37,8 +40,9 @@ for k, v in res.items():
     if "hbm_read_MB" in v and "hbm_write_MB" in v:
         v["hbm_traffic_MB"] = v["hbm_read_MB"] + v["hbm_write_MB"]
         if v.get("avg_active_us"):
-            v["hbm_GBps"] = v["hbm_traffic_MB"] / v["avg_active_us"] * 1e3 / 1e3
+            v["hbm_GBps"] = v["hbm_traffic_MB"] / v["avg_active_us"] * 1e3   # MB/us = TB/s
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1, sort_keys=True)
+json.dump(pmc, open(f"{out}/pmc_extract.json", "w"), indent=1, sort_keys=True)
 for k in sorted(res, key=lambda k: -res[k].get("total_ms", 0)):
     v = res[k]
     print(f"{k:22s} n={v.get('launches',0):5d} active={v.get('active_launches',0):5d} avg={v.get('avg_active_us',0):8.1f} us total={v.get('total_ms',0):8.2f} ms "
