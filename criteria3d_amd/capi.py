@@ -125,6 +125,10 @@ SIGNATURES = {
     "sf3d_get_nodes_water_content": (u8, [u32, u32, pd]),
     "sf3d_get_nodes_water_conductivity": (u8, [u32, u32, pd]),
     "sf3d_get_nodes_boundary_water_flow": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_temperature": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_heat_sink_source": (u8, [u32, u32, pd]),
+    "sf3d_get_nodes_temperature": (u8, [u32, u32, pd]),
+    "sf3d_set_nodes_boundary_heat": (u8, [i32, u32, p32, pd]),
     "sf3d_get_counters": (u8, [p64]),
     "sf3d_get_time_step": (f64, []),
     "sf3d_set_time_step": (u8, [f64]),
@@ -149,6 +153,10 @@ REFERENCE_API = [k for k in SIGNATURES if k != "sf3d_backend_name"][:70]
 
 COUNTER_NAMES = ["attempts", "accepted", "approximations", "sweeps", "courant_rejections",
                  "linear_failures", "restores", "reserved"]
+
+
+BOUNDARY_HEAT_FIELDS = ("height_wind", "height_temperature", "roughness", "temperature", "relative_humidity",
+                        "wind_speed", "net_irradiance")
 
 
 class SF3DError(RuntimeError):
@@ -250,6 +258,23 @@ class SF3D:
 
     def boundary_water_flow(self, first, count):
         return self._get_f64(self.lib.sf3d_get_nodes_boundary_water_flow, first, count, "get_nodes_boundary_water_flow")
+
+    def set_temperature_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_temperature, first, v, "set_nodes_temperature")
+
+    def set_heat_sink_source_bulk(self, first, v):
+        self._set_f64(self.lib.sf3d_set_nodes_heat_sink_source, first, v, "set_nodes_heat_sink_source")
+
+    def temperature(self, first, count):
+        return self._get_f64(self.lib.sf3d_get_nodes_temperature, first, count, "get_nodes_temperature")
+
+    def set_boundary_heat_bulk(self, field, nodes, values):
+        """field: one of BOUNDARY_HEAT_FIELDS (name or index)"""
+        f = BOUNDARY_HEAT_FIELDS.index(field) if isinstance(field, str) else int(field)
+        nodes = _arr(nodes, np.uint32)
+        values = _arr(np.broadcast_to(np.asarray(values, np.float64), nodes.shape), np.float64)
+        self.check(self.lib.sf3d_set_nodes_boundary_heat(f, len(nodes), _ptr(nodes, u32), _ptr(values, f64)),
+                   f"set_nodes_boundary_heat[{field}]")
 
     def counters(self):
         out = (u64 * 8)()

@@ -168,7 +168,58 @@ def catchment_model(nx: int, ny: int, nz: int, heterogeneous: bool = False, cell
                  cell_area=area, shape=(nx, ny, nz), meta=dict(kind="catchment", heterogeneous=heterogeneous))
 
 
-def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool = True):
+@dataclass
+class Heat:
+    """Coupled heat transport set-up of a Model (heat.cpp): which processes run, the initial soil
+    temperature, the HeatSurface boundary nodes with their static atmosphere geometry and the
+    fixed-temperature bottom boundary."""
+    water: bool = True                 # isComputeWater
+    advection: bool = False            # initializeHeatFlag(.., isComputeAdvectiveFlux, ..)
+    latent: bool = True                # initializeHeatFlag(.., .., isComputeLatentHeat)
+    save_mode: int = 2                 # heatFluxSaveMode_t: 0 None, 1 Total, 2 All
+    t0_surface: float = 288.15         # initial temperature at the top soil node [K] ...
+    t0_gradient: float = -2.0          # ... plus this many K per metre of depth below the surface
+    height_wind: float = 2.0
+    height_temperature: float = 2.0
+    roughness_height: float = 0.01
+    fixed_temperature: float = 285.15  # bottom (FreeDrainage) boundary
+    fixed_depth: float = 0.5
+
+
+def heat_surface_nodes(m: Model) -> np.ndarray:
+    """first soil node below every surface node (the nodes that carry the atmosphere boundary)"""
+    down = m.link_dir == capi.LINK_DOWN
+    src = m.link_node[down]
+    top = src < m.ns
+    return m.link_to[down][top].astype(np.uint32)
+
+
+def with_heat_surface(m: Model) -> Model:
+    """copy of the model whose top soil nodes without another boundary are HeatSurface nodes"""
+    import copy
+    m = copy.deepcopy(m)
+    top = heat_surface_nodes(m)
+    top = top[m.btype[top] == capi.BND_NONE]
+    m.btype[top] = capi.BND_HEAT_SURFACE
+    m.bslope[top] = 0.0
+    m.barea[top] = m.cell_area
+    return m
+
+
+def heat_forcing(h: int) -> dict:
+    """synthetic hourly atmosphere at the HeatSurface nodes: diurnal air temperature, humidity, wind, net irradiance"""
+    ph = 2.0 * np.pi * ((h + 8) % 24) / 24.0
+    return dict(temperature=288.15 + 6.0 * np.sin(ph - np.pi / 2), relative_humidity=65.0 - 20.0 * np.sin(ph - np.pi / 2),
+                wind_speed=2.0 + 1.0 * np.cos(ph), net_irradiance=max(0.0, 350.0 * np.sin(ph - np.pi / 2)) - 40.0)
+
+
+def apply_heat_forcing(sf: capi.SF3D, m: Model, h: int):
+    nodes = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE).astype(np.uint32)
+    for k, v in heat_forcing(h).items():
+        sf.set_boundary_heat_bulk(k, nodes, v)
+
+
+def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool = True, heat: Heat | None = None):
     """Push a Model through the ABI in the caller's order.
 
     dist = (rank, world, allgather) shards the model over `world` ranks (HIP product only):
@@ -177,7 +228,11 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
     if dist is not None:
         rank, world, allgather = dist
         sf.check(sf.lib.sf3d_dist_prepare(rank, world), "dist_prepare")
-    sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
+    if heat is None:
+        sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
+    else:
+        sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, int(heat.water), 1, 0, heat.save_mode), "initialize")
+        sf.check(sf.lib.sf3d_initialize_heat_flag(heat.save_mode, int(heat.advection), int(heat.latent)), "initialize_heat_flag")
     sf.check(sf.lib.sf3d_set_surface_properties(0, m.roughness), "set_surface_properties")
     for k, s in enumerate(m.soils):
         sf.check(sf.lib.sf3d_set_soil_properties(k, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"],
@@ -194,9 +249,30 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
              "set_hydraulic_properties")
     sf.check(sf.lib.sf3d_set_numerical_parameters(*m.numerics), "set_numerical_parameters")
     sf.lib.sf3d_set_threads_number(threads)
+    if heat is not None:
+        # temperatures first: with latent heat the conductivity set by the potential setters has a vapour term
+        up = m.link_dir == capi.LINK_UP
+        parent = np.arange(m.n)
+        parent[m.link_node[up]] = m.link_to[up]
+        root = parent.copy()
+        for _ in range(64):
+            nxt = parent[root]
+            if np.array_equal(nxt, root):
+                break
+            root = nxt
+        depth = m.z[root] - m.z
+        sf.set_temperature_bulk(0, heat.t0_surface + heat.t0_gradient * depth)
     psi = np.full(m.n, m.psi0_soil)
     psi[:m.ns] = m.psi0_surface
     sf.set_matric_potential_bulk(0, psi)
+    if heat is not None:
+        hs = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE).astype(np.uint32)
+        sf.set_boundary_heat_bulk("height_wind", hs, heat.height_wind)
+        sf.set_boundary_heat_bulk("height_temperature", hs, heat.height_temperature)
+        sf.set_boundary_heat_bulk("roughness", hs, heat.roughness_height)
+        apply_heat_forcing(sf, m, 0)
+        for i in np.flatnonzero(m.btype == capi.BND_FREE_DRAINAGE):
+            sf.check(sf.lib.sf3d_set_node_boundary_fixed_temperature(int(i), heat.fixed_temperature, heat.fixed_depth), "fixed_temperature")
     if not finalize:          # host-side staging only (partition queries on a machine without a GPU)
         return
     if dist is not None:

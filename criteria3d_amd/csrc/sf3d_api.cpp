@@ -528,6 +528,19 @@ BULK_GET(sf3d_get_nodes_degree_of_saturation, sf3d_get_node_degree_of_saturation
 BULK_GET(sf3d_get_nodes_water_content, sf3d_get_node_water_content)
 BULK_GET(sf3d_get_nodes_water_conductivity, sf3d_get_node_water_conductivity)
 BULK_GET(sf3d_get_nodes_boundary_water_flow, sf3d_get_node_boundary_water_flow)
+BULK_SET(sf3d_set_nodes_temperature, sf3d_set_node_temperature(first + k, v[k]), const double* v)
+BULK_SET(sf3d_set_nodes_heat_sink_source, sf3d_set_node_heat_sink_source(first + k, v[k]), const double* v)
+BULK_GET(sf3d_get_nodes_temperature, sf3d_get_node_temperature)
+sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint32_t* nodes, const double* v)
+{
+    typedef sf3d_error_t (*setter_t)(uint32_t, double);
+    static const setter_t setters[7] = {sf3d_set_node_boundary_height_wind, sf3d_set_node_boundary_height_temperature,
+        sf3d_set_node_boundary_roughness, sf3d_set_node_boundary_temperature, sf3d_set_node_boundary_relative_humidity,
+        sf3d_set_node_boundary_wind_speed, sf3d_set_node_boundary_net_irradiance};
+    if (field < 0 || field > 6) return SF3D_PARAMETER_ERROR;
+    for (uint32_t k = 0; k < count; ++k) { const sf3d_error_t e = setters[field](nodes[k], v[k]); if (e != SF3D_OK) return e; }
+    return SF3D_OK;
+}
 
 sf3d_error_t sf3d_get_counters(uint64_t out[8])
 {

@@ -200,7 +200,9 @@ double sf3d_get_water_storage(void);
 /* getWaterMBR                    soilFluxes3D.h:73  soilFluxes3D.cpp:1274-1277 */
 double sf3d_get_water_mbr(void);
 
-/* ---- heat setters (state is stored; heat transport itself is SURVEY.md 8f-2, "next") -- */
+/* ---- heat setters (heat transport: heat.cpp, heatLoop cpusolver.cpp:471-605).
+ * Where the reference would write through arrays it only allocates when isComputeHeat was requested
+ * (soilFluxes3D.cpp:100-165) these return SF3D_MISSING_DATA_ERROR instead of crashing. -------------- */
 
 /* setNodeHeatSinkSource             soilFluxes3D.h:76  soilFluxes3D.cpp:1283-1294 */
 sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t nodeIndex, double heatSinkSource);
@@ -292,6 +294,16 @@ sf3d_error_t sf3d_get_nodes_degree_of_saturation(uint32_t first, uint32_t count,
 sf3d_error_t sf3d_get_nodes_water_content(uint32_t first, uint32_t count, double* out);
 sf3d_error_t sf3d_get_nodes_water_conductivity(uint32_t first, uint32_t count, double* out);
 sf3d_error_t sf3d_get_nodes_boundary_water_flow(uint32_t first, uint32_t count, double* out);
+/* heat counterparts: setNodeTemperature / setNodeHeatSinkSource / getNodeTemperature over a range
+ * (surface nodes answer getNodeTemperature's TopographyError value, soilFluxes3D.cpp:1496-1497) */
+sf3d_error_t sf3d_set_nodes_temperature(uint32_t first, uint32_t count, const double* temperature);
+sf3d_error_t sf3d_set_nodes_heat_sink_source(uint32_t first, uint32_t count, const double* q);
+sf3d_error_t sf3d_get_nodes_temperature(uint32_t first, uint32_t count, double* out);
+/* one atmospheric boundary field for a list of nodes = count calls of the scalar setter of
+ * soilFluxes3D.h:79-85 (same validation; stops at the first error):
+ * field 0 heightWind, 1 heightTemperature, 2 roughness, 3 temperature, 4 relativeHumidity,
+ * 5 windSpeed, 6 netIrradiance */
+sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint32_t* nodes, const double* values);
 
 /* Work counters since sf3d_initialize (the same events SURVEY.md App. B instruments in
  * cpusolver.cpp): out[0] attempts (waterMainLoop iterations), [1] accepted steps,

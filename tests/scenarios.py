@@ -126,6 +126,88 @@ def soil_only(sf, threads=1):
     return _hours(sf, m, [(0.0, None, True), (0.0, None, True)], threads, pre=_ragged_pre)
 
 
+HEAT_SCALARS = ("total_water", "storage", "heat_storage", "heat_mbr", "heat_mbe")
+FLUX_TYPES = 9
+
+
+def _heat_hours(sf, m, heat, plan, threads=1, use_period=False, flux_nodes=()):
+    """plan: list of (rain_mm, keep_arrays).  Hourly atmosphere from cm.heat_forcing(h)."""
+    sf.lib.sf3d_reset_solver_state()
+    cm.build(sf, m, threads=threads, heat=heat)
+    hs = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE)
+    soil = np.arange(m.ns, m.n)
+    out, scal = {}, {k: [] for k in HEAT_SCALARS}
+    bnd = {k: [] for k in ("sensible", "latent", "radiative", "aerodynamic", "soil_conductance", "evaporation")}
+    nsteps, alldts = [], []
+    for h, (mm, keep) in enumerate(plan):
+        cm.apply_heat_forcing(sf, m, h)
+        steps, dts = cm.run_hour(sf, m, mm, use_period=use_period)
+        if dts is not None:
+            nsteps.append(steps); alldts.extend(dts)
+        H = sf.total_potential(0, m.n)
+        scal["total_water"].append(sf.lib.sf3d_get_total_water_content())
+        scal["storage"].append(sf.lib.sf3d_get_water_storage())
+        scal["heat_storage"].append(sum(sf.lib.sf3d_get_node_heat_storage(int(i), float(H[i] - m.z[i])) for i in soil))
+        scal["heat_mbr"].append(sf.lib.sf3d_get_heat_mbr()); scal["heat_mbe"].append(sf.lib.sf3d_get_heat_mbe())
+        L = sf.lib
+        bnd["sensible"].append([L.sf3d_get_node_boundary_sensible_flux(int(i)) for i in hs])
+        bnd["latent"].append([L.sf3d_get_node_boundary_latent_flux(int(i)) for i in hs])
+        bnd["radiative"].append([L.sf3d_get_node_boundary_radiative_flux(int(i)) for i in hs])
+        bnd["aerodynamic"].append([L.sf3d_get_node_boundary_aerodynamic_conductance(int(i)) for i in hs])
+        bnd["soil_conductance"].append([L.sf3d_get_node_boundary_soil_conductance(int(i)) for i in hs])
+        bnd["evaporation"].append([L.sf3d_get_node_boundary_water_flow(int(i)) for i in hs])
+        if keep:
+            out[f"T_h{h}"] = sf.temperature(0, m.n); out[f"H_h{h}"] = H
+            out[f"conductivity_h{h}"] = np.array([L.sf3d_get_node_heat_conductivity(int(i)) for i in soil])
+            if flux_nodes:
+                out[f"flux_h{h}"] = np.array([[[L.sf3d_get_node_heat_max_flux(int(i), d, t) for t in range(FLUX_TYPES)]
+                                               for d in (capi.LINK_UP, capi.LINK_DOWN, capi.LINK_LATERAL)] for i in flux_nodes])
+    for k in HEAT_SCALARS:
+        out[k] = np.array(scal[k])
+    for k, v in bnd.items():
+        out["boundary_" + k] = np.array(v)
+    out["steps_per_hour"] = np.array(nsteps, np.int64)
+    out["dts"] = np.array(alldts)
+    return out
+
+
+def heat_column_conduction(sf, threads=1):
+    """heat only (isComputeWater = false): conduction in a 1.05 m column under a diurnal atmosphere, all link fluxes saved"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    return _heat_hours(sf, m, cm.Heat(water=False, latent=False, save_mode=2), [(0.0, h in (0, 11)) for h in range(12)],
+                       threads, flux_nodes=(1, 2, 10, 21))
+
+
+def heat_column_water(sf, threads=1):
+    """water + heat without vapour: thermal liquid fluxes in the water rows, total heat flux saved"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=False, save_mode=1), [(1.0 if h == 0 else 0.0, h in (0, 5)) for h in range(6)],
+                       threads, flux_nodes=(1, 2, 10, 21))
+
+
+def heat_column_latent(sf, threads=1):
+    """water + heat + latent heat: vapour conductivity / capacity terms, evaporation boundary, all fluxes saved"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=True, save_mode=2), [(1.0 if h == 0 else 0.0, h in (0, 5)) for h in range(6)],
+                       threads, flux_nodes=(1, 2, 10, 21))
+
+
+def heat_column_period(sf, threads=1):
+    """the same through computePeriod: whole-period heat balance (getHeatMBR / getHeatMBE)"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=True, save_mode=0), [(0.5 if h == 0 else 0.0, h == 3) for h in range(4)],
+                       threads, use_period=True)
+
+
+def heat_catchment_latent(sf, threads=1):
+    """24 x 24 x 6 tilted catchment, heterogeneous soils, every top soil cell an atmosphere boundary: lateral conduction,
+    evaporation from ponded cells (surface water fraction), fixed-temperature bottom"""
+    m = cm.with_heat_surface(cm.catchment_model(24, 24, 6, heterogeneous=True))
+    mid = m.ns + 24 * 12 + 12
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=True, save_mode=1), [(4.0 if h == 0 else 0.0, h in (0, 2)) for h in range(3)],
+                       threads, flux_nodes=(mid, mid + m.ns))
+
+
 SCENARIOS = {
     "c1_column": c1_column,
     "c1_column_period": c1_column_period,
@@ -138,7 +220,13 @@ SCENARIOS = {
     "ravone_window": ravone_window,
     "surface_only": surface_only,
     "soil_only": soil_only,
+    "heat_column_conduction": heat_column_conduction,
+    "heat_column_water": heat_column_water,
+    "heat_column_latent": heat_column_latent,
+    "heat_column_period": heat_column_period,
+    "heat_catchment_latent": heat_catchment_latent,
 }
+HEAT_SCENARIOS = tuple(k for k in SCENARIOS if k.startswith("heat_"))
 
 
 def run_scenario(sf, name, threads=1):
