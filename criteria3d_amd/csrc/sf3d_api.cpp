@@ -25,7 +25,9 @@ std::vector<std::vector<uint16_t>> soil1D;      /* soil1DIndices, soilFluxes3D.c
 bool useLineal = false; int linealMethod = 0;
 struct Bal { double storage = 0, sinkSource = 0, MBE = 0, MBR = 0; };
 Bal curPeriod, wholePeriod;                     /* period balances live on the host (computePeriod) */
-double heatMBR = 0., heatMBE = 0.;
+struct HeatBal { double storage = 0, sinkSource = 0, MBE = 0, MBR = 0; };
+HeatBal heatCurPeriod, heatWholePeriod;         /* balanceDataCurrentPeriod / WholePeriod, heat members */
+struct HeatFlagsHost { bool vapor = false, advection = false; uint8_t save = 0; } HF;   /* simulationFlags_t: survives re-initialisation */
 uint64_t counterBase[8] = {0};
 
 DeviceSolver& dev() { return DeviceSolver::instance(); }
@@ -74,6 +76,25 @@ double mualemK(const SoilHost& s, double Se)                        /* :181-214 
     return s.Ksat * std::pow(Se, s.L) * (temp * temp);
 }
 double thetaFromSe(const SoilHost& s, double Se) { return (Se * (s.thetaS - s.thetaR)) + s.thetaR; }   /* :38-42 */
+/* computeNodeK as the state setters call it (soilFluxes3D.cpp:831,859,881,903): Mualem + the isothermal vapour
+ * conductivity when latent heat is on (soilPhysics.cpp:164-172, heat.cpp:831-845, 1080-1087, 1136-1176) */
+double nodeKHost(uint32_t i)
+{
+    const SoilHost& s = M.soils[M.cls[i]];
+    double k = mualemK(s, M.Se[i]);
+    if (M.heat && HF.vapor) {
+        const double T = (M.temperature[i] + M.temperature[i]) * 0.5;      /* temperature == oldTemperature outside a step */
+        const double h = M.H[i] - M.z[i];
+        const double theta = (h >= 0.) ? s.thetaS : thetaFromSe(s, seFromPsi(s, std::fabs(h)));
+        const double vDiff = (0.0000212 * std::pow(T / 273.15, 2.)) * 0.66 * std::pow(s.thetaS - theta, 1.);
+        const double svp = 611 * std::exp(17.502 * (T - 273.15) / ((T - 273.15) + 240.97));
+        const double svc = (svp * 0.018 / (8.31447215 * T));
+        const double rh = std::exp(0.018 * h * 9.80665 / (8.31447215 * T));
+        const double vConc = svc * rh;
+        k += ((vDiff * vConc * 0.018) / (8.31447215 * T)) * (9.80665 / 1000.);
+    }
+    return k;
+}
 double nodeTheta(uint32_t i) { return M.surf[i] ? 1. : thetaFromSe(M.soils[M.cls[i]], M.Se[i]); }      /* :26-32 */
 double thetaFromSignedPsi(uint32_t i, double psi)                   /* :50-61 */
 {
@@ -138,11 +159,13 @@ sf3d_error_t sf3d_clean(void)                                       /* soilFluxe
     return SF3D_OK;
 }
 
-sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h, int s, sf3d_heat_save_t)   /* :49-178 */
+sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h, int s, sf3d_heat_save_t saveMode)   /* :49-178 */
 {
     sf3d_error_t c = sf3d_clean();
     if (c != SF3D_OK) return c;
     M.water = w != 0; M.heat = h != 0; M.solutes = s != 0;
+    if (M.heat) { HF.vapor = true; HF.advection = true; HF.save = saveMode; }        /* :58-65 */
+    M.heatVapor = HF.vapor; M.heatAdvection = HF.advection; M.heatSave = HF.save;
     M.N = n; M.ns = ns;
     if (nLat > 8) return SF3D_PARAMETER_ERROR;
     try {
@@ -151,13 +174,17 @@ sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h
         reset(M.bflowRate, n); reset(M.bflowSum, n); reset(M.prescribed, n); reset(M.nLat, n);
         for (int k = 0; k < SF3D_SLOTS; ++k) { reset(M.ltype[k], n); reset(M.lto[k], n); reset(M.larea[k], n); reset(M.lflowSum[k], n); }
         reset(M.Se, n); reset(M.K, n); reset(M.H, n); reset(M.sink, n); reset(M.pond, n);
-        if (M.heat) { reset(M.temperature, n); reset(M.heatSink, n); }
+        if (M.heat) {
+            for (auto* v : {&M.temperature, &M.heatSink, &M.bHeightWind, &M.bHeightT, &M.bRoughH, &M.bT, &M.bRH, &M.bWind, &M.bNetIrr,
+                            &M.bFixT, &M.bFixDepth, &M.bAero, &M.bSoilCond, &M.bSens, &M.bLat, &M.bRad, &M.bAdv}) reset(*v, n);
+        }
     } catch (const std::bad_alloc&) { return SF3D_MEMORY_ERROR; }
     M.initialized = true;
     if (P.dtCurr == SF3D_NODATA) P.dtCurr = P.dtMax;               /* CPUSolver::initialize, cpusolver.cpp:30-31 */
     M.solverReady = true;
     std::memset(counterBase, 0, sizeof(counterBase));
     curPeriod = Bal(); wholePeriod = Bal();
+    heatCurPeriod = HeatBal(); heatWholePeriod = HeatBal();
     return SF3D_OK;
 }
 
@@ -178,12 +205,30 @@ sf3d_error_t sf3d_initialize_balance(void)                          /* soilFluxe
     for (int k = 0; k < SF3D_SLOTS; ++k) std::fill(M.lflowSum[k].begin(), M.lflowSum[k].end(), 0.);
     std::fill(M.bflowSum.begin(), M.bflowSum.end(), 0.);
     M.flowSumsDirty = true;
-    if (!M.heat) heatMBR = 1.;
+    if (M.heat) {                                                   /* initializeHeatBalance, heat.cpp:31-53 */
+        double hs = 0.;
+        e = dev().heat_storage(M, P, &hs);
+        if (e != SF3D_OK) { fprintf(stderr, "sf3d: initializeBalance (heat): %s\n", dev().last_error()); return e; }
+        Ctrl& ch = dev().ctrl();
+        heatWholePeriod = HeatBal(); heatCurPeriod = HeatBal();
+        heatWholePeriod.storage = heatCurPeriod.storage = hs;
+        ch.heatCur = HeatBalanceDev{hs, 0., 0., 0.}; ch.heatPrev = HeatBalanceDev{hs, 0., 0., 0.};
+        ch.heatPeriodSink = 0.;
+        dev().push_ctrl();
+    } else heatWholePeriod.MBR = 1.;
     return SF3D_OK;
 }
 sf3d_error_t sf3d_initialize_log(const char*, const char*) { return SF3D_OK; }   /* MCR logging is not built (parallel.pri:15-16) */
 sf3d_error_t sf3d_close_log(void) { return SF3D_OK; }
-sf3d_error_t sf3d_initialize_heat_flag(sf3d_heat_save_t, int, int) { return SF3D_OK; }
+sf3d_error_t sf3d_initialize_heat_flag(sf3d_heat_save_t save, int adv, int latent)   /* soilFluxes3D.cpp:325-332 */
+{
+    HF.save = save; HF.advection = adv != 0; HF.vapor = latent != 0;
+    if (M.initialized && (M.heatSave != HF.save || M.heatAdvection != HF.advection || M.heatVapor != HF.vapor)) {
+        M.heatVapor = HF.vapor; M.heatAdvection = HF.advection; M.heatSave = HF.save;
+        M.graphDirty = true;                  /* which flux arrays exist and which kernels' terms are live change */
+    }
+    return SF3D_OK;
+}
 
 uint32_t sf3d_set_threads_number(uint32_t n)                        /* soilFluxes3D.cpp:340-361: clamp and report; the GPU path has no host threads to set */
 {
@@ -270,6 +315,13 @@ sf3d_error_t sf3d_set_node_boundary(uint32_t i, sf3d_boundary_t bt, double slope
         M.bflowRate[i] = 0.; M.bflowSum[i] = 0.; M.prescribed[i] = SF3D_NODATA;
         M.flowSumsDirty = true;
     }
+    if (M.heat) {                                                   /* soilFluxes3D.cpp:706-722 */
+        M.bHeightWind[i] = M.bHeightT[i] = M.bRoughH[i] = M.bAero[i] = M.bSoilCond[i] = SF3D_NODATA;
+        M.bT[i] = M.bRH[i] = M.bWind[i] = M.bNetIrr[i] = SF3D_NODATA;
+        M.bRad[i] = M.bLat[i] = M.bSens[i] = M.bAdv[i] = 0.;
+        M.bFixT[i] = M.bFixDepth[i] = SF3D_NODATA;
+        M.heatBoundaryDirty = true;
+    }
     return SF3D_OK;
 }
 sf3d_error_t sf3d_set_node(uint32_t i, double x, double y, double z, double v, int isSurf, sf3d_boundary_t bt,
@@ -339,7 +391,7 @@ sf3d_error_t sf3d_set_node_water_content(uint32_t i, double wc)     /* soilFluxe
         const SoilHost& s = M.soils[M.cls[i]];
         M.Se[i] = seFromTheta(s, wc);
         M.H[i] = M.z[i] - nodePsi(i);
-        M.K[i] = mualemK(s, M.Se[i]);
+        M.K[i] = nodeKHost(i);
     }
     M.stateDirty = true;
     return SF3D_OK;
@@ -352,7 +404,7 @@ sf3d_error_t sf3d_set_node_degree_of_saturation(uint32_t i, double se)   /* soil
     if (!needState()) return SF3D_SOLVER_ERROR;
     M.Se[i] = se;
     M.H[i] = M.z[i] - nodePsi(i);
-    M.K[i] = mualemK(M.soils[M.cls[i]], M.Se[i]);
+    M.K[i] = nodeKHost(i);
     M.stateDirty = true;
     return SF3D_OK;
 }
@@ -361,7 +413,7 @@ static sf3d_error_t setH(uint32_t i, double H)                      /* soilFluxe
     if (!needState()) return SF3D_SOLVER_ERROR;
     M.H[i] = H;
     if (M.surf[i]) { M.Se[i] = 1.; M.K[i] = SF3D_NODATA; }
-    else { M.Se[i] = nodeSe(i); M.K[i] = mualemK(M.soils[M.cls[i]], M.Se[i]); }
+    else { M.Se[i] = nodeSe(i); M.K[i] = nodeKHost(i); }
     M.stateDirty = true;
     return SF3D_OK;
 }
@@ -433,33 +485,91 @@ double sf3d_get_total_water_content(void)                           /* soilFluxe
 double sf3d_get_water_storage(void) { return dev().ctrl().curStep.storage; }
 double sf3d_get_water_mbr(void) { return wholePeriod.MBR; }
 
-/* ---- heat: state is staged when heat was requested; transport is not implemented (8f-2) ---- */
+/* ---- heat setters / getters (soilFluxes3D.cpp:1283-1752).  Without isComputeHeat the reference's arrays do not
+ * exist: MissingDataError.  Getters pull device results lazily. ---- */
 #define HEAT_OFF_E if (!M.heat) return SF3D_MISSING_DATA_ERROR
-sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.heatSink[i] = v; return SF3D_OK; }
-sf3d_error_t sf3d_set_node_temperature(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.temperature[i] = v; return SF3D_OK; }
-#define HEAT_BND_SET(NAME) sf3d_error_t NAME(uint32_t i, double) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; \
-    if (M.btype[i] == SF3D_BND_NONE) return SF3D_BOUNDARY_ERROR; return SF3D_MISSING_DATA_ERROR; }
-HEAT_BND_SET(sf3d_set_node_boundary_height_wind) HEAT_BND_SET(sf3d_set_node_boundary_height_temperature)
-HEAT_BND_SET(sf3d_set_node_boundary_net_irradiance) HEAT_BND_SET(sf3d_set_node_boundary_temperature)
-HEAT_BND_SET(sf3d_set_node_boundary_relative_humidity) HEAT_BND_SET(sf3d_set_node_boundary_roughness)
-HEAT_BND_SET(sf3d_set_node_boundary_wind_speed)
-sf3d_error_t sf3d_set_node_boundary_fixed_temperature(uint32_t i, double, double) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; return SF3D_MISSING_DATA_ERROR; }
+#define HEAT_OFF_D if (!M.heat) return errValue(SF3D_MISSING_DATA_ERROR)
+static bool needHeat()
+{
+    if (M.hostStaleHeat && dev().ready())
+        if (dev().fetch_heat(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+    return true;
+}
+sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.heatSink[i] = v; M.heatSinkDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_set_node_temperature(uint32_t i, double v)
+{ NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; needHeat(); M.temperature[i] = v; M.heatStateDirty = true; return SF3D_OK; }
+sf3d_error_t sf3d_set_node_boundary_fixed_temperature(uint32_t i, double t, double depth)
+{
+    NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E;
+    if (M.btype[i] != SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL && M.btype[i] != SF3D_BND_FREE_DRAINAGE) return SF3D_BOUNDARY_ERROR;
+    M.bFixT[i] = t; M.bFixDepth[i] = depth; M.heatBoundaryDirty = true;
+    return SF3D_OK;
+}
+#define HEAT_BND_SET(NAME, FIELD, CHECK) sf3d_error_t NAME(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; \
+    if (M.btype[i] == SF3D_BND_NONE) return SF3D_BOUNDARY_ERROR; CHECK; M.FIELD[i] = v; M.heatBoundaryDirty = true; return SF3D_OK; }
+HEAT_BND_SET(sf3d_set_node_boundary_height_wind, bHeightWind, )
+HEAT_BND_SET(sf3d_set_node_boundary_height_temperature, bHeightT, )
+HEAT_BND_SET(sf3d_set_node_boundary_net_irradiance, bNetIrr, )
+HEAT_BND_SET(sf3d_set_node_boundary_temperature, bT, )
+HEAT_BND_SET(sf3d_set_node_boundary_relative_humidity, bRH, )
+HEAT_BND_SET(sf3d_set_node_boundary_roughness, bRoughH, if (v < 0) return SF3D_PARAMETER_ERROR)
+HEAT_BND_SET(sf3d_set_node_boundary_wind_speed, bWind, if ((v < 0.) || (v > 1000.)) return SF3D_PARAMETER_ERROR)
+
 double sf3d_get_node_temperature(uint32_t i)
-{ NEED_INIT_D; NEED_NODE_D(i); if (!M.heat || M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); return M.temperature[i]; }
-#define HEAT_GET(NAME) double NAME(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
-HEAT_GET(sf3d_get_node_heat_conductivity) HEAT_GET(sf3d_get_node_vapor)
-HEAT_GET(sf3d_get_node_boundary_advective_flux) HEAT_GET(sf3d_get_node_boundary_latent_flux)
-HEAT_GET(sf3d_get_node_boundary_radiative_flux) HEAT_GET(sf3d_get_node_boundary_sensible_flux)
-HEAT_GET(sf3d_get_node_boundary_aerodynamic_conductance) HEAT_GET(sf3d_get_node_boundary_soil_conductance)
-double sf3d_get_node_heat_storage(uint32_t i, double) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
-double sf3d_get_node_heat_max_flux(uint32_t i, sf3d_link_t, sf3d_flux_t) { NEED_INIT_D; NEED_NODE_D(i); return errValue(SF3D_MISSING_DATA_ERROR); }
-double sf3d_get_heat_mbr(void) { return heatMBR; }
-double sf3d_get_heat_mbe(void) { return heatMBE; }
+{ NEED_INIT_D; NEED_NODE_D(i); if (!M.heat || M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); if (!needHeat()) return std::nan(""); return M.temperature[i]; }
+static double heatQuery(int what, uint32_t i, double h)
+{
+    double out = std::nan("");
+    if (dev().heat_query(M, P, what, i, h, &out) != SF3D_OK) fprintf(stderr, "sf3d: heat query failed: %s\n", dev().last_error());
+    return out;
+}
+double sf3d_get_node_heat_conductivity(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (!M.heat || M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); return heatQuery(0, i, 0.); }
+double sf3d_get_node_vapor(uint32_t i)
+{ NEED_INIT_D; NEED_NODE_D(i); if (!M.water || !M.heat || !M.heatVapor) return errValue(SF3D_MISSING_DATA_ERROR); if (M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); return heatQuery(1, i, 0.); }
+double sf3d_get_node_heat_storage(uint32_t i, double h)
+{ NEED_INIT_D; NEED_NODE_D(i); HEAT_OFF_D; if (M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR); return heatQuery(2, i, h); }
+static double linkHeatFlux(int slot, uint32_t i, sf3d_flux_t t)                              /* getLinkHeatFlux, heat.cpp:639-658 */
+{
+    if (!M.heat) return SF3D_NODATA;
+    if (M.heatSave == 1) { if (t != 0) return SF3D_NODATA; }
+    else if (M.heatSave != 2 || t >= SF3D_FLUX_TYPES) return SF3D_NODATA;
+    if (!M.lfluxValid[t]) {
+        if (!dev().ready()) return (M.ltype[slot][i] != SF3D_LINK_NONE) ? SF3D_NODATA : 0.;   /* setNodeLink initialisation */
+        if (dev().fetch_link_flux(M, t) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return std::nan(""); }
+    }
+    return M.lfluxCache[t][(size_t)slot * M.N + i];
+}
+double sf3d_get_node_heat_max_flux(uint32_t i, sf3d_link_t dir, sf3d_flux_t t)              /* soilFluxes3D.cpp:1580-1612 */
+{
+    NEED_INIT_D; NEED_NODE_D(i);
+    if (!M.heat || M.surf[i]) return errValue(SF3D_TOPOGRAPHY_ERROR);
+    switch (dir) {
+        case SF3D_LINK_UP: return linkHeatFlux(0, i, t);
+        case SF3D_LINK_DOWN: return linkHeatFlux(1, i, t);
+        case SF3D_LINK_LATERAL: {
+            double mx = 0.;
+            for (int l = 0; l < 8; ++l) { const double f = linkHeatFlux(2 + l, i, t); if (f > std::fabs(mx)) mx = f; }
+            return mx; }
+        default: return errValue(SF3D_INDEX_ERROR);
+    }
+}
+#define HEAT_BND_GET(NAME, FIELD, NEEDS_VAPOR) double NAME(uint32_t i) { NEED_INIT_D; NEED_NODE_D(i); \
+    if (NEEDS_VAPOR ? (!M.water || !M.heat || !M.heatVapor) : !M.heat) return errValue(SF3D_MISSING_DATA_ERROR); \
+    if (M.btype[i] != SF3D_BND_HEAT_SURFACE) return errValue(SF3D_BOUNDARY_ERROR); if (!needHeat()) return std::nan(""); return M.FIELD[i]; }
+HEAT_BND_GET(sf3d_get_node_boundary_advective_flux, bAdv, true)
+HEAT_BND_GET(sf3d_get_node_boundary_latent_flux, bLat, true)
+HEAT_BND_GET(sf3d_get_node_boundary_radiative_flux, bRad, false)
+HEAT_BND_GET(sf3d_get_node_boundary_sensible_flux, bSens, false)
+HEAT_BND_GET(sf3d_get_node_boundary_aerodynamic_conductance, bAero, false)
+HEAT_BND_GET(sf3d_get_node_boundary_soil_conductance, bSoilCond, false)
+double sf3d_get_heat_mbr(void) { return heatWholePeriod.MBR; }
+double sf3d_get_heat_mbe(void) { return heatWholePeriod.MBE; }
 
 /* ---- computation ---- */
 double sf3d_compute_step(double maxDt)                               /* soilFluxes3D.cpp:1785-1821 */
 {
-    if (!M.water) return std::min(maxDt, P.dtMax);
+    if (!M.water && !M.heat) return std::min(maxDt, P.dtMax);
     if (!M.initialized || !M.solverReady) { fprintf(stderr, "sf3d: computeStep before initializeSF3D\n"); return std::nan(""); }
     double dt = std::nan("");
     sf3d_error_t e = dev().step(M, P, maxDt, &dt);
@@ -472,7 +582,7 @@ double sf3d_compute_step(double maxDt)                               /* soilFlux
 void sf3d_compute_period(double period)                              /* soilFluxes3D.cpp:1760-1777, water.cpp:143-156 */
 {
     if (!M.initialized) return;
-    if (dev().ready()) { dev().ctrl().curPeriod.sinkSource = 0.; dev().push_ctrl(); }
+    if (dev().ready()) { dev().ctrl().curPeriod.sinkSource = 0.; dev().ctrl().heatPeriodSink = 0.; dev().push_ctrl(); }
     double t = 0.;
     while (t < period) {
         const double dt = sf3d_compute_step(period - t);
@@ -490,6 +600,18 @@ void sf3d_compute_period(double period)                              /* soilFlux
         const double ref = std::max(0.001, wholePeriod.sinkSource);
         wholePeriod.MBR = wholePeriod.MBE / ref;
         curPeriod.storage = c.curStep.storage;
+    }
+    if (M.heat) {                                                   /* updateHeatBalanceDataWholePeriod, heat.cpp:400-413 */
+        const Ctrl& c = dev().ctrl();
+        heatCurPeriod.sinkSource = c.heatPeriodSink;
+        heatWholePeriod.sinkSource += heatCurPeriod.sinkSource;
+        const double dSp = c.heatCur.storage - heatCurPeriod.storage;
+        const double dSh = c.heatCur.storage - heatWholePeriod.storage;
+        heatCurPeriod.MBE = dSp - heatCurPeriod.sinkSource;
+        heatWholePeriod.MBE = dSh - heatWholePeriod.sinkSource;
+        const double ref = std::max(1., std::fabs(heatWholePeriod.sinkSource));
+        heatWholePeriod.MBR = heatWholePeriod.MBE / ref;
+        heatCurPeriod.storage = c.heatCur.storage;
     }
 }
 

@@ -52,6 +52,7 @@ struct alignas(16) sf3d_d2 { double x, y; };
 
 struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
+    double clay, organicMatter;   /* heat only */
 };
 
 /* per-chunk link descriptor (144 bytes, fetched through the scalar path once per chunk) */
@@ -66,6 +67,21 @@ struct ChunkDesc {
 };
 
 struct BalanceDev { double storage, sinkSource, MBE, MBR; };
+struct HeatBalanceDev { double storage, sinkSource, MBE, MBR; };
+
+/* stages of the heat part of a computeStep (soilFluxes3D.cpp:1802-1818, CPUSolver::run(Heat)
+ * cpusolver.cpp:77-91, heatLoop :471-605): three nested loops driven on the device */
+enum : uint32_t {
+    HS_IDLE = 0,
+    HS_SAVE_WATER = 1,  /* saveWaterFluxValues: link water / vapour fluxes of the accepted water step  */
+    HS_BOUNDARY = 2,    /* updateBoundaryHeatData + boundary Courant check                              */
+    HS_ASSEMBLE = 3,    /* heatLoop: node properties, then rows                                          */
+    HS_SWEEP = 4,       /* iterations of the heat linear system                                          */
+    HS_POST = 5,        /* evaluateHeatBalance                                                           */
+    HS_SAVE = 6,        /* saveHeatFluxValues of an accepted heat step                                   */
+    HS_FINISHED = 7
+};
+#define SF3D_FLUX_TYPES 9   /* numTotalFluxTypes, types.h:28 */
 
 struct Ctrl {
     /* ---- parameters (SolverParameters, types.h:291-315) ---- */
@@ -87,6 +103,16 @@ struct Ctrl {
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
     /* ---- balances (balanceData_t x4, soilFluxes3D.cpp:37) ---- */
     BalanceDev curStep, prevStep, curPeriod, wholePeriod;
+    /* ---- heat part of the step ---- */
+    uint32_t hStage, hIter, hIterBudget, hRows;
+    int32_t tCur, tOld;       /* indices into the temperature pool (Told = T and T = Told are index copies) */
+    uint32_t hSweepsLast, hPad;
+    double dtWater;           /* accepted water step (or min(maxTimeStep, dtMax) without water)          */
+    double hOuterDt, hOuterSum;   /* dtHeat / dtHeatSum of computeStep's loop                            */
+    double hMaxStep, hDt, hDone;  /* maxTimeStep / dtHeat / sumHeatTime of CPUSolver::run(Heat)          */
+    double hCourant, hNorm;
+    HeatBalanceDev heatCur, heatPrev;
+    double heatPeriodSink;    /* balanceDataCurrentPeriod.heatSinkSource                                 */
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
     /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
@@ -120,6 +146,27 @@ struct DistView {
     const uint8_t* bndLane; const uint8_t* bndPeer; const uint32_t* bndSlot;
 };
 /* payload layout per (receiver, source p): [parity 0/1][field 0/1][count] doubles at offset off[p] */
+
+/* coupled heat transport (heat.cpp): everything the heat kernels and the heat terms of the water kernels
+ * need; `on` = 0 leaves every pointer null */
+struct HeatDev {
+    uint32_t on, water, vapor, advection, save;    /* simulationFlags_t, types.h:189-197 */
+    double wf;                                      /* heatWeightFactor, types.h:307 */
+    double* TX[3];                                  /* temperature pool: T, Told and the sweep buffers are indices (Ctrl::tCur/tOld) */
+    const double* heatSink;
+    double *heatFlux, *invariant;                   /* heatData.heatFlux, waterData.invariantFluxes */
+    double *hC, *hcapTerm, *hb, *hD;                /* heat capacity x V, water-content-change term, rhs, diagonal */
+    sf3d_d2* hA2;                                   /* [5][N] normalised off-diagonals (slots paired like A2); 0 where the slot is no heat link */
+    const double* hdist;                            /* [10][N] nodeDistance3D of every link between two soil nodes */
+    /* per-node conductivities evaluated once per node instead of once per link end (same arguments => same bits) */
+    double *kHeat, *kIsoVap;                        /* heat process: Campbell conductivity, isothermal vapour conductivity at (T, mean h) */
+    double *wThLiq, *wThVap, *wTm;                  /* water process: thermal liquid / vapour conductivity at (mean T, H - z); mean T */
+    /* atmosphere boundary (HeatSurface nodes) and fixed-temperature boundary, full-length arrays */
+    const double *bHeightWind, *bHeightT, *bRoughH, *bT, *bRH, *bWind, *bNetIrr, *bFixT, *bFixDepth;
+    double *bAero, *bSoilCond, *bSens, *bLat, *bRad, *bAdv;
+    double *lwaterFlux, *lvaporFlux;                /* [10][N], values rounded through float like the reference */
+    double* lflux[SF3D_FLUX_TYPES];                 /* [10][N] each; allocated per heatFluxSaveMode_t */
+};
 
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
@@ -157,6 +204,7 @@ struct DevView {
     const SoilDev* soils;
     const double* roughness;
     Ctrl* ctrl;
+    HeatDev heat;
 };
 
 /* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */

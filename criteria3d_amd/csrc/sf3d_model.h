@@ -26,6 +26,7 @@ struct ParamsHost {                    /* SolverParameters, types.h:291-315 (per
     uint16_t maxApprox = 10, maxIter = 200;
     uint8_t wrc = SF3D_WRC_MODIFIED_VAN_GENUCHTEN, meanType = SF3D_MEAN_LOGARITHMIC;
     double lvRatio = 4., courantThreshold = 0.5, instabilityFactor = 10.;
+    double heatWeightFactor = 0.5;     /* types.h:307 */
     uint32_t numThreads = 1;
 };
 
@@ -45,8 +46,14 @@ struct HostModel {
     std::vector<double> Se, K, H, sink, pond;
     std::vector<SoilHost> soils;
     std::vector<double> roughness;
-    /* heat state is staged only (transport: SURVEY.md 8f-2) */
+    /* coupled heat transport (heat.cpp): flags, state, atmosphere / fixed-temperature boundary inputs, boundary outputs */
+    bool heatVapor = false, heatAdvection = false; uint8_t heatSave = 0;
     std::vector<double> temperature, heatSink;
+    std::vector<double> bHeightWind, bHeightT, bRoughH, bT, bRH, bWind, bNetIrr, bFixT, bFixDepth;
+    std::vector<double> bAero, bSoilCond, bSens, bLat, bRad, bAdv;
+    std::vector<double> lfluxCache[SF3D_FLUX_TYPES]; bool lfluxValid[SF3D_FLUX_TYPES] = {false};   /* [10][N], fetched on demand */
+    bool heatStateDirty = true, heatSinkDirty = true, heatBoundaryDirty = true;
+    bool hostStaleHeat = false;      /* temperature and boundary outputs are newer on the device */
 
     /* what the device lacks */
     bool graphDirty = true;      /* topology / classes / boundary geometry: rebuild + full upload */
@@ -94,6 +101,11 @@ public:
     sf3d_error_t total_water_content(HostModel& m, const ParamsHost& p, double* out);
     sf3d_error_t fetch_state(HostModel& m);      /* H, Se, K   -> host */
     sf3d_error_t fetch_flows(HostModel& m);      /* flow sums  -> host */
+    /* heat */
+    sf3d_error_t fetch_heat(HostModel& m);       /* temperature, boundary fluxes and conductances -> host */
+    sf3d_error_t fetch_link_flux(HostModel& m, int type);   /* one flux type [10][N] -> m.lfluxCache[type] */
+    sf3d_error_t heat_query(HostModel& m, const ParamsHost& p, int what, uint32_t node, double h, double* out);
+    sf3d_error_t heat_storage(HostModel& m, const ParamsHost& p, double* out);   /* computeCurrentHeatStorage() */
     sf3d_error_t release();
     sf3d_error_t synchronize();
     Ctrl& ctrl() { return mirror_; }

@@ -173,56 +173,6 @@ __device__ __forceinline__ double dtheta_dh(const SoilDev& s, double H, double H
     return dSe * (s.thetaS - s.thetaR);
 }
 
-/* ---- waterFlow = sink (+ evaporation clamp) + boundary flow (water.cpp:632-807) ---- */
-__device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c, uint32_t i, double H, double Ho,
-                                                double z, double K)
-{
-    const double dt = c->dt;
-    double flow = v.sink[i];
-    if (i < v.ns && flow < 0) {                                       /* :646-652 */
-        const double avgH = 0.5 * (H + Ho);
-        const double hs = dmax(0., avgH - z);
-        const double maxFlux = -hs * v.size[i] / dt;
-        flow = dmax(flow, maxFlux);
-    }
-    const uint8_t bt = v.btype[i];
-    if (bt != SF3D_BND_NONE) {
-        double rate = 0.;
-        switch (bt) {
-            case SF3D_BND_RUNOFF: {                                   /* :661-678 */
-                const double avgH = 0.5 * (H + Ho);
-                const double hs = dmax(0., avgH - (z + v.pond[i]));
-                if (hs < 0.001) break;
-                const double maxFlow = (hs * v.size[i]) / dt;
-                const double vel = pow(hs, 2. / 3.) * sqrt(v.bslope[i]) / v.roughness[v.cls[i]];
-                const double val = hs * vel * v.bsize[i];
-                rate = -dmin(val, maxFlow);
-                break; }
-            case SF3D_BND_FREE_DRAINAGE:                              /* :680-684, Up-link area */
-                rate = -K * v.larea[i];
-                break;
-            case SF3D_BND_FREE_LATERAL_DRAINAGE:                      /* :686-690 */
-                rate = -K * v.bsize[i] * v.bslope[i] * c->lvRatio;
-                break;
-            case SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL: {               /* :692-706 */
-                const SoilDev s = v.soils[v.cls[i]];
-                const double L = 1.;
-                const double bz = z - L;
-                const double pH = v.prescribed[i];
-                const double bpsi = pH - bz;
-                const double bK = (bpsi >= 0) ? s.Ksat : mualem_k(s, se_from_psi(s, fabs(bpsi), c->wrc), c->wrc);
-                const double mk = mean_of(bK, K, c->meanType);
-                rate = mk * v.bsize[i] * ((pH - H) / L);
-                break; }
-            default: rate = 0.; break;                                /* Urban/Road/Culvert/HeatSurface w/o heat */
-        }
-        if (fabs(rate) < DBL_EPSILON) rate = 0.;                      /* :802-805 */
-        else flow += rate;
-        v.bflowRate[i] = rate;
-    }
-    v.flow[i] = flow;
-}
-
 /* ======================================================================================= */
 /* multi-GPU exchange (device side)                                                          */
 /* ======================================================================================= */
@@ -593,6 +543,107 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
  * per-node owner map covers the general case */
 #define NOT_MINE(v, i) ((i) >= (v).N || ((v).owner != nullptr && (v).owner[i] != (v).rank))
 
+#include "sf3d_heat.inc"
+
+/* ---- waterFlow = sink (+ evaporation clamp) + boundary flow (water.cpp:632-807) ---- */
+template <bool HEAT>
+__device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c, uint32_t i, double H, double Ho,
+                                                double z, double K, double Se)
+{
+    const double dt = c->dt;
+    double flow = v.sink[i];
+    if (i < v.ns && flow < 0) {                                       /* :646-652 */
+        const double avgH = 0.5 * (H + Ho);
+        const double hs = dmax(0., avgH - z);
+        const double maxFlux = -hs * v.size[i] / dt;
+        flow = dmax(flow, maxFlux);
+    }
+    const uint8_t bt = v.btype[i];
+    double rate = 0.;
+    if (bt != SF3D_BND_NONE) {
+        switch (bt) {
+            case SF3D_BND_RUNOFF: {                                   /* :661-678 */
+                const double avgH = 0.5 * (H + Ho);
+                const double hs = dmax(0., avgH - (z + v.pond[i]));
+                if (hs < 0.001) break;
+                const double maxFlow = (hs * v.size[i]) / dt;
+                const double vel = pow(hs, 2. / 3.) * sqrt(v.bslope[i]) / v.roughness[v.cls[i]];
+                const double val = hs * vel * v.bsize[i];
+                rate = -dmin(val, maxFlow);
+                break; }
+            case SF3D_BND_FREE_DRAINAGE:                              /* :680-684, Up-link area */
+                rate = -K * v.larea[i];
+                break;
+            case SF3D_BND_FREE_LATERAL_DRAINAGE:                      /* :686-690 */
+                rate = -K * v.bsize[i] * v.bslope[i] * c->lvRatio;
+                break;
+            case SF3D_BND_PRESCRIBED_TOTAL_POTENTIAL: {               /* :692-706 */
+                const SoilDev s = v.soils[v.cls[i]];
+                const double L = 1.;
+                const double bz = z - L;
+                const double pH = v.prescribed[i];
+                const double bpsi = pH - bz;
+                const double bK = (bpsi >= 0) ? s.Ksat : mualem_k(s, se_from_psi(s, fabs(bpsi), c->wrc), c->wrc);
+                const double mk = mean_of(bK, K, c->meanType);
+                rate = mk * v.bsize[i] * ((pH - H) / L);
+                break; }
+            case SF3D_BND_HEAT_SURFACE: {                             /* :708-747: soil evaporation / condensation */
+                if (!HEAT || !v.heat.vapor) break;
+                const HeatDev& hv = v.heat;
+                const SoilDev s = v.soils[v.cls[i]];
+                const uint32_t up = v.lto[i];                         /* slot 0; node 0 when there is no Up link, like the reference */
+                const bool upLinked = v.lkind[i] != LK_NONE;
+                double frac = 0.;
+                if (upLinked && up < v.ns) {                          /* getNodeSurfaceWaterFraction, soilPhysics.cpp:317-326 */
+                    const double hV = dmax(0., v.X[c->cur][up] - v.z[up]);
+                    frac = dmin(1., hV / dmax(0.001, v.pond[up]));
+                }
+                double evap = 0.;
+                if (up < v.ns) {                                      /* computeNodeAtmosphericLatentVaporFlux, heat.cpp:988-1008 */
+                    const double Ta = hv.bT[i];
+                    const double satC = h_vapor_conc_from_pressure(h_sat_vapor_pressure(Ta - H_ZEROC), Ta);
+                    const double boundaryVapor = satC * (hv.bRH[i] / 100.);
+                    const double dVapor = boundaryVapor - h_vapor_from_psi_temp(H - z, hv.TX[c->tCur][i]);
+                    const double total = 1. / ((1. / hv.bAero[i]) + (1. / hv.bSoilCond[i]));
+                    evap = dVapor * total;
+                }
+                evap = evap / H_RHOW * v.larea[i];
+                if (frac > 0.) evap *= (1. - frac);
+                const double thetaV = (Se * (s.thetaS - s.thetaR)) + s.thetaR;
+                rate = (evap < 0.) ? dmax(evap, -(thetaV - s.thetaR) * v.size[i] / dt)
+                                   : dmin(evap, (s.thetaS - s.thetaR) * v.size[i] / dt);
+                break; }
+            default: rate = 0.; break;                                /* Urban/Road/Culvert */
+        }
+        if (fabs(rate) < DBL_EPSILON) rate = 0.;                      /* :802-805 */
+        else flow += rate;
+    }
+    if (HEAT && i < v.ns && v.heat.vapor && v.lkind[(size_t)v.N + i] != LK_NONE) {
+        /* evaporation of ponded water (water.cpp:719-733).  The reference lets the HeatSurface node below write
+         * into this node; here the surface node pulls: same values, same order (this node's own boundary first) */
+        const HeatDev& hv = v.heat;
+        const uint32_t d = v.lto[(size_t)v.N + i];                    /* slot 1 = Down */
+        if (v.btype[d] == SF3D_BND_HEAT_SURFACE && v.lkind[d] != LK_NONE && v.lto[d] == i) {
+            const double hV = dmax(0., H - z);
+            const double frac = dmin(1., hV / dmax(0.001, v.pond[i]));
+            if (frac > 0.) {                                          /* computeNodeAtmosphericLatentSurfaceWaterFlux, heat.cpp:1014-1039 */
+                const double Ta = hv.bT[d];
+                const double satC = h_vapor_conc_from_pressure(h_sat_vapor_pressure(Ta - H_ZEROC), Ta);
+                const double boundaryVapor = satC * (hv.bRH[d] / 100.);
+                double surfEvap = ((boundaryVapor - satC) * hv.bAero[d]) / H_RHOW * v.larea[d];
+                surfEvap *= frac;
+                const double volume = (H - z) * v.size[i];
+                surfEvap = dmax(surfEvap, -volume / dt);
+                if (bt != SF3D_BND_NONE) rate = surfEvap;             /* overwrites the rate, waterFlow keeps the runoff already added */
+                else flow += surfEvap;
+            }
+        }
+    }
+    if (bt != SF3D_BND_NONE) v.bflowRate[i] = rate;
+    v.flow[i] = flow;
+}
+
+
 /* dtheta/dH with the two saturation degrees already known (soilPhysics.cpp:224-279):
  * Se(psiCurr) is the Se array (post-solve of the previous approximation, same H) and Se(psiPrev)
  * is SeHold (written at approximation 0, when H == Hold) - the same values the reference
@@ -619,7 +670,7 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
 
 /* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
  * updateBoundaryWaterData (water.cpp:632-807) */
-template <int MODE>
+template <int MODE, bool HEAT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -635,16 +686,33 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
         double K = 0., fl = 0.;
         if (mine) {
             const double H = Xc[i], Ho = Xh[i], z = v.z[i];
+            double Se = 1.;
             if (i >= v.ns) {
                 const SoilDev s = v.soils[v.cls[i]];
-                double Se, SeH;
+                double SeH;
                 if (first) { Se = node_se(s, H, z, wrc); SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se; }
                 else { Se = v.Se[i]; SeH = v.SeHold[i]; }
                 K = mualem_k(s, Se, wrc);
+                const double dThdH = dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
+                double C = v.size[i] * dThdH;
+                if (HEAT) {                                   /* vapour terms of computeNodeK / computeCapacity + the node
+                                                                 conductivities of the thermal fluxes in the water rows */
+                    const HeatDev& hv = v.heat;
+                    const double Tm = (hv.TX[c->tCur][i] + hv.TX[c->tOld][i]) * 0.5;   /* getNodeMeanTemperature */
+                    const double h = H - z;
+                    const double theta = h_theta_signed_psi(s, h, wrc);
+                    if (hv.vapor) {
+                        K += h_isothermal_vapor_conductivity(s, Tm, h, theta) * (H_G / H_RHOW);
+                        C += v.size[i] * h_dthetav_dh(s, h, Tm, dThdH, wrc);
+                        hv.wThVap[i] = h_thermal_vapor_conductivity(s, z, Tm, h, theta);
+                    }
+                    hv.wTm[i] = Tm;
+                    hv.wThLiq[i] = h_thermal_liquid_conductivity(Tm - H_ZEROC, h, K);
+                }
                 v.K[i] = K;
-                v.C[i] = v.size[i] * dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
+                v.C[i] = C;
             }
-            boundary_update(v, c, i, H, Ho, z, K);
+            boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
             if (MODE == 2) fl = v.flow[i];
         }
         if (MODE == 2) { dist_put_chunk(v, q, lane_, par, 0, K); dist_put_chunk(v, q, lane_, par, 1, fl); }
@@ -737,9 +805,22 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
 /* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
  * computeDiagonalElement (:335-345) + preconditioningMatrix (:284-305), in two kernels like the
  * reference's two loops (surface rows, Courant check, soil rows - cpusolver.cpp:412-429). */
+/* thermal liquid (+ vapour) flux of one soil-soil link in the water rows: computeThermalLiquidFlux /
+ * computeThermalVaporFlux with processType::Water (heat.cpp:469-567), added to invariantFluxes (water.cpp:328-340) */
+__device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i, uint32_t j, double area, double dist3, double& inv)
+{
+    const double Ti = hv.wTm[i], Tj = hv.wTm[j];
+    const double avgL = mean_of(hv.wThLiq[i], hv.wThLiq[j], SF3D_MEAN_LOGARITHMIC);
+    inv += (avgL * (Tj - Ti) / dist3) * area;
+    if (hv.vapor) {
+        const double avgV = mean_of(hv.wThVap[i], hv.wThVap[j], SF3D_MEAN_LOGARITHMIC);
+        inv += ((avgV * (Tj - Ti) / dist3) * area) / H_RHOW;
+    }
+}
+
 template <bool NT>
 __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&k)[SF3D_SLOTS],
-                                          double sum, double Hoi, double dt)
+                                          double sum, double Hoi, double dt, double invariantFlux)
 {
     const double Ci = (i < v.ns) ? v.size[i] : v.C[i];            /* surface capacity = area, cpusolver.cpp:151 */
     const double cdt = Ci / dt;
@@ -749,12 +830,12 @@ __device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd,
         if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) {
             store_coeff<NT>(&v.A2[(size_t)p * v.N + i], (k[2 * p] * -1.) * inv, (k[2 * p + 1] * -1.) * inv);
         }
-    v.b[i] = ((cdt * Hoi) + v.flow[i] + 0.0) * inv;
+    v.b[i] = ((cdt * Hoi) + v.flow[i] + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
 }
 
 /* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
  * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
-template <bool NT>
+template <bool NT, bool HEAT>
 __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
@@ -772,7 +853,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
         const ChunkDesc cd = v.cdesc[q];
         const double Hi = Xc[i], Hoi = Xh[i], zi = v.z[i];
         double k[SF3D_SLOTS];
-        double sum = 0.;
+        double sum = 0., invFlux = 0.;
         #pragma unroll
         for (int o = 0; o < SF3D_SLOTS; ++o) {
             const uint32_t s = order[o];
@@ -783,11 +864,12 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
                 if (cd.kind[s] != CK_MIXED) { kind = cd.kind[s]; j = i + cd.delta[s]; }
                 else { kind = v.lkind[e]; j = v.lto[e]; }
                 if (kind != LK_NONE) ks = link_conductance(v, c, i, j, e, kind, Xc, Xh, Hi, Hoi, zi, courant);
+                if (HEAT && (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT)) add_thermal_fluxes(v.heat, i, j, v.larea[e], v.heat.hdist[e], invFlux);
             }
             k[s] = ks;
             sum += ks;
         }
-        store_row<NT>(v, cd, i, k, sum, Hoi, dt);
+        store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
     }
     return block_max(courant);
 }
@@ -798,7 +880,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
-template <bool NT>
+template <bool NT, bool HEAT>
 __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
@@ -816,7 +898,7 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
         const double Hoi = Xh[i], Ki = v.K[i];
         double k[SF3D_SLOTS];
-        double sum = 0.;
+        double sum = 0., invFlux = 0.;
         #pragma unroll
         for (int g = 0; g < 2; ++g) {
             uint32_t j[5]; uint8_t kd[5];
@@ -847,24 +929,26 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
                     ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
                 }                                                            /* a soil row has no runoff link */
+                if (HEAT && (kd[t] == LK_SOIL_LAT || kd[t] == LK_SOIL_VERT))
+                    add_thermal_fluxes(v.heat, i, j[t], area[t], v.heat.hdist[(size_t)s * v.N + i], invFlux);
                 k[s] = ks;
                 sum += ks;
             }
         }
-        store_row<NT>(v, cd, i, k, sum, Hoi, dt);
+        store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
     }
 }
 
 /* one launch: blocks [0, nbSurf) assemble the surface rows (and reduce the Courant maximum),
  * blocks [nbSurf, nbSurf + nbSoil) the soil rows.  FUSED: the block that arrives last takes the
  * Courant decision (checkCourant) instead of a separate one-block kernel. */
-template <bool FUSED, bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASM_WAVES) k_assemble(DevView v)
+template <bool FUSED, bool NT, bool HEAT>
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
     double bm = 0.;
-    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT>(v, blockIdx.x, v.nbSurf);
-    else assemble_soil_rows<NT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
+    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT>(v, blockIdx.x, v.nbSurf);
+    else assemble_soil_rows<NT, HEAT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
     if (!FUSED) {
         if (threadIdx.x == 0 && blockIdx.x < v.nbSurf) v.part0[blockIdx.x] = bm;
         return;
@@ -988,7 +1072,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
 }
 
 /* restoreBestStep, water.cpp:253-267 */
-template <bool FUSED>
+template <bool FUSED, bool HEAT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
 {
     const Ctrl* c = v.ctrl;
@@ -1005,9 +1089,14 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
             const SoilDev s = v.soils[v.cls[i]];
             Se = node_se(s, H, z, c->wrc);
             K = mualem_k(s, Se, c->wrc);
+            if (HEAT && v.heat.vapor) {
+                const HeatDev& hv = v.heat;
+                const double Tm = (hv.TX[c->tCur][i] + hv.TX[c->tOld][i]) * 0.5;
+                K += h_isothermal_vapor_conductivity(s, Tm, H - z, h_theta_signed_psi(s, H - z, c->wrc)) * (H_G / H_RHOW);
+            }
             v.Se[i] = Se; v.K[i] = K;
         }
-        boundary_update(v, c, i, H, Ho, z, K);
+        boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
         balance_terms(v, c, i, H, z, Se, st, sk);
     }
     const double a = block_sum(st), b = block_sum(sk);
@@ -1163,6 +1252,8 @@ struct DeviceSolver::Impl {
     uint32_t N = 0, ns = 0;
     uint32_t lastSweeps = 8;
     uint32_t lastBatches = 1;
+    uint32_t lastHeatSweeps = 8;
+    double* heatOut[6] = {nullptr};       /* bAero, bSoilCond, bSens, bLat, bRad, bAdv (device) */
     /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
     int useFused = -1;                     /* SF3D_FUSED_DECIDE=0 keeps the separate decision kernel */
@@ -1276,7 +1367,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         if (world_ > 1 && connected_) { snprintf(err_, sizeof(err_), "topology changed after sf3d_dist_connect: export/connect again"); }
         /* pull anything newer on the device before the arrays are re-created */
-        if (built_) { if (m.hostStaleState) fetch_state(m); if (m.hostStaleFlows) fetch_flows(m); }
+        if (built_) { if (m.hostStaleState) fetch_state(m); if (m.hostStaleFlows) fetch_flows(m); if (m.heat && m.hostStaleHeat && I.v.heat.on) fetch_heat(m); }
         release();
         I.N = N; I.ns = ns;
         DevView& v = I.v;
@@ -1484,10 +1575,64 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
         v.cdesc = dcdesc;
 
+        if (m.heat) {       /* coupled heat transport: state, system, per-node conductivities, boundary and link flux arrays */
+            if (world_ > 1) { snprintf(err_, sizeof(err_), "heat transport is not sharded across GPUs yet (isComputeHeat with %d ranks)", world_); return SF3D_PARAMETER_ERROR; }
+            HeatDev& hv = v.heat;
+            hv = HeatDev{};
+            hv.on = 1; hv.water = m.water ? 1u : 0u; hv.vapor = m.heatVapor ? 1u : 0u; hv.advection = m.heatAdvection ? 1u : 0u;
+            hv.save = m.heatSave; hv.wf = p.heatWeightFactor;
+            double* tmp = nullptr;
+            for (int k = 0; k < 3; ++k) { HIP_TRY(dev_alloc(I.allocs, hv.TX[k], N)); HIP_TRY(hipMemset(hv.TX[k], 0, N * 8)); }
+            auto alloc0 = [&](double*& ptr, size_t cnt) -> hipError_t { hipError_t e = dev_alloc(I.allocs, ptr, cnt); if (e == hipSuccess) e = hipMemset(ptr, 0, cnt * 8); return e; };
+            HIP_TRY(alloc0(tmp, N)); hv.heatSink = tmp;
+            HIP_TRY(alloc0(hv.heatFlux, N)); HIP_TRY(alloc0(hv.invariant, N));
+            HIP_TRY(alloc0(hv.hC, N)); HIP_TRY(alloc0(hv.hcapTerm, N)); HIP_TRY(alloc0(hv.hb, N)); HIP_TRY(alloc0(hv.hD, N));
+            HIP_TRY(dev_alloc(I.allocs, hv.hA2, NS / 2)); HIP_TRY(hipMemset(hv.hA2, 0, NS * 8));
+            HIP_TRY(alloc0(hv.kHeat, N)); HIP_TRY(alloc0(hv.kIsoVap, N));
+            HIP_TRY(alloc0(hv.wThLiq, N)); HIP_TRY(alloc0(hv.wThVap, N)); HIP_TRY(alloc0(hv.wTm, N));
+            const double** inputs[9] = {&hv.bHeightWind, &hv.bHeightT, &hv.bRoughH, &hv.bT, &hv.bRH, &hv.bWind, &hv.bNetIrr, &hv.bFixT, &hv.bFixDepth};
+            for (auto* pp : inputs) { HIP_TRY(alloc0(tmp, N)); *pp = tmp; }
+            double** outputs[6] = {&hv.bAero, &hv.bSoilCond, &hv.bSens, &hv.bLat, &hv.bRad, &hv.bAdv};
+            const std::vector<double>* outInit[6] = {&m.bAero, &m.bSoilCond, &m.bSens, &m.bLat, &m.bRad, &m.bAdv};   /* NODATA / 0 of setNodeBoundary */
+            for (int k = 0; k < 6; ++k) {
+                HIP_TRY(alloc0(*outputs[k], N)); I.heatOut[k] = *outputs[k];
+                HIP_TRY(hipMemcpy(*outputs[k], outInit[k]->data(), N * 8, hipMemcpyHostToDevice));
+            }
+            HIP_TRY(alloc0(hv.lwaterFlux, NS)); HIP_TRY(alloc0(hv.lvaporFlux, NS));
+            const int nTypes = (m.heatSave == 2) ? SF3D_FLUX_TYPES : (m.heatSave == 1 ? 1 : 0);
+            {   /* never-linked slots hold 0 (calloc in the reference), linked slots NODATA (setNodeLink, soilFluxes3D.cpp:672-678) */
+                std::vector<double> init(NS, 0.);
+                for (size_t e = 0; e < NS; ++e) if (kind[e] != LK_NONE) init[e] = NODATA_D;
+                for (int t = 0; t < nTypes; ++t) {
+                    HIP_TRY(dev_alloc(I.allocs, hv.lflux[t], NS));
+                    HIP_TRY(hipMemcpy(hv.lflux[t], init.data(), NS * 8, hipMemcpyHostToDevice));
+                }
+            }
+            {   /* nodeDistance3D (soilPhysics.cpp:334-338) of every link between two soil nodes */
+                std::vector<double> d3(NS, 1.);
+                parallel_for(N, [&](uint32_t a, uint32_t b) {
+                    for (uint32_t i = a; i < b; ++i)
+                        for (int s = 0; s < SF3D_SLOTS; ++s) {
+                            const size_t e = (size_t)s * N + i;
+                            if (kind[e] != LK_SOIL_VERT && kind[e] != LK_SOIL_LAT) continue;
+                            const uint32_t j = to[e];
+                            const double dx = m.x[i] - m.x[j], dy = m.y[i] - m.y[j], dz = m.z[i] - m.z[j];
+                            double nrm = 0; nrm += dx * dx; nrm += dy * dy; nrm += dz * dz;
+                            d3[e] = std::sqrt(nrm);
+                        }
+                });
+                HIP_TRY(alloc0(tmp, NS)); hv.hdist = tmp;
+                HIP_TRY(hipMemcpy(tmp, d3.data(), NS * 8, hipMemcpyHostToDevice));
+            }
+            m.heatStateDirty = m.heatSinkDirty = m.heatBoundaryDirty = true;
+            m.hostStaleHeat = false;
+            for (int t = 0; t < SF3D_FLUX_TYPES; ++t) m.lfluxValid[t] = false;
+        }
+
         std::vector<SoilDev> sd(m.soils.size());
         for (size_t k = 0; k < sd.size(); ++k) {
             const SoilHost& s = m.soils[k];
-            sd[k] = SoilDev{s.alpha, s.n, s.m, s.he, s.Sc, 1.0 / s.Sc, s.thetaS, s.thetaR, s.Ksat, s.L, 1.0 / s.m, s.mualemDen};
+            sd[k] = SoilDev{s.alpha, s.n, s.m, s.he, s.Sc, 1.0 / s.Sc, s.thetaS, s.thetaR, s.Ksat, s.L, 1.0 / s.m, s.mualemDen, s.clay, s.organicMatter};
         }
         HIP_TRY(hipMemcpy(z, m.z.data(), N * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(size, m.size.data(), N * 8, hipMemcpyHostToDevice));
@@ -1507,6 +1652,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         std::memset(&mirror_, 0, sizeof(mirror_));
         mirror_.cur = 0; mirror_.hold = 0; mirror_.best = -1; mirror_.stage = ST_IDLE;
         mirror_.bestMBR = NODATA_D;
+        mirror_.tCur = 0; mirror_.tOld = 0; mirror_.hStage = HS_IDLE;
         built_ = true;
         m.graphDirty = false;
         m.stateDirty = m.sinkDirty = m.pondDirty = m.boundaryDirty = m.flowSumsDirty = m.ctrlDirty = true;
@@ -1534,6 +1680,21 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         for (int s = 0; s < SF3D_SLOTS; ++s)
             HIP_TRY(hipMemcpyAsync(v.lflowSum + (size_t)s * N, m.lflowSum[s].data(), N * 8, hipMemcpyHostToDevice, I.stream));
         m.flowSumsDirty = false;
+    }
+    if (v.heat.on) {
+        HeatDev& hv = v.heat;
+        if (m.heatStateDirty) {      /* setNodeTemperature sets temperature and oldTemperature (soilFluxes3D.cpp:1308-1309) */
+            if (mirror_.tOld != mirror_.tCur) { mirror_.tOld = mirror_.tCur; m.ctrlDirty = true; }
+            HIP_TRY(hipMemcpyAsync(hv.TX[mirror_.tCur], m.temperature.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+            m.heatStateDirty = false;
+        }
+        if (m.heatSinkDirty) { HIP_TRY(hipMemcpyAsync((void*)hv.heatSink, m.heatSink.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.heatSinkDirty = false; }
+        if (m.heatBoundaryDirty) {
+            const std::vector<double>* src[9] = {&m.bHeightWind, &m.bHeightT, &m.bRoughH, &m.bT, &m.bRH, &m.bWind, &m.bNetIrr, &m.bFixT, &m.bFixDepth};
+            const double* dst[9] = {hv.bHeightWind, hv.bHeightT, hv.bRoughH, hv.bT, hv.bRH, hv.bWind, hv.bNetIrr, hv.bFixT, hv.bFixDepth};
+            for (int k = 0; k < 9; ++k) HIP_TRY(hipMemcpyAsync((void*)dst[k], src[k]->data(), N * 8, hipMemcpyHostToDevice, I.stream));
+            m.heatBoundaryDirty = false;
+        }
     }
     if (m.ctrlDirty || ctrlEdited_) {
         fill_params(mirror_, p);
@@ -1567,6 +1728,61 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
         HIP_TRY(hipMemcpyAsync(m.lflowSum[s].data(), I.v.lflowSum + (size_t)s * N, N * 8, hipMemcpyDeviceToHost, I.stream));
     HIP_TRY(hipStreamSynchronize(I.stream));
     m.hostStaleFlows = false;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::fetch_heat(HostModel& m)
+{
+    Impl& I = *impl_;
+    const size_t N = m.N;
+    if (!I.v.heat.on) return SF3D_OK;
+    HIP_TRY(hipMemcpyAsync(m.temperature.data(), I.v.heat.TX[mirror_.tCur], N * 8, hipMemcpyDeviceToHost, I.stream));
+    std::vector<double>* dst[6] = {&m.bAero, &m.bSoilCond, &m.bSens, &m.bLat, &m.bRad, &m.bAdv};
+    for (int k = 0; k < 6; ++k) HIP_TRY(hipMemcpyAsync(dst[k]->data(), I.heatOut[k], N * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    m.hostStaleHeat = false;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::fetch_link_flux(HostModel& m, int type)
+{
+    Impl& I = *impl_;
+    if (type < 0 || type >= SF3D_FLUX_TYPES || !I.v.heat.on || !I.v.heat.lflux[type]) return SF3D_MISSING_DATA_ERROR;
+    const size_t NS = (size_t)m.N * SF3D_SLOTS;
+    m.lfluxCache[type].resize(NS);
+    HIP_TRY(hipMemcpyAsync(m.lfluxCache[type].data(), I.v.heat.lflux[type], NS * 8, hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    m.lfluxValid[type] = true;
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::heat_query(HostModel& m, const ParamsHost& p, int what, uint32_t node, double h, double* out)
+{
+    sf3d_error_t e = sync_to_device(m, p);
+    if (e != SF3D_OK) return e;
+    Impl& I = *impl_;
+    if (!I.v.heat.on) return SF3D_MISSING_DATA_ERROR;
+    hipLaunchKernelGGL(k_heat_query, dim3(1), dim3(1), 0, I.stream, I.v, what, node, h);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&I.hostCtrl->query[1], &I.v.ctrl->query[1], sizeof(double), hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    *out = I.hostCtrl->query[1];
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::heat_storage(HostModel& m, const ParamsHost& p, double* out)
+{
+    sf3d_error_t e = sync_to_device(m, p);
+    if (e != SF3D_OK) return e;
+    Impl& I = *impl_;
+    if (!I.v.heat.on) return SF3D_MISSING_DATA_ERROR;
+    hipLaunchKernelGGL(k_heat_storage, dim3(I.v.nb), dim3(SF3D_BLOCK), 0, I.stream, I.v);
+    hipLaunchKernelGGL(k_decide_query, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(I.hostCtrl, I.v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, I.stream));
+    HIP_TRY(hipStreamSynchronize(I.stream));
+    mirror_ = *I.hostCtrl;
+    *out = mirror_.query[0];
     return SF3D_OK;
 }
 
@@ -1666,6 +1882,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const DevView& v = I.v;
     const dim3 grid(v.nb), block(SF3D_BLOCK), one(1);
     const bool multi = world_ > 1;
+    const bool heatOn = v.heat.on != 0;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
@@ -1684,8 +1901,15 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         I.pending.push_back({a, b, kid});
     };
 
+    if (heatOn) {                           /* computeStep head, soilFluxes3D.cpp:1787-1791 */
+        if (v.heat.save == 2) hipLaunchKernelGGL(k_heat_reset_water_fluxes, grid, block, 0, st, v);
+        hipLaunchKernelGGL(k_heat_conductance, grid, block, 0, st, v);
+        for (int t = 0; t < SF3D_FLUX_TYPES; ++t) m.lfluxValid[t] = false;
+    }
+    uint32_t stage = ST_ACCEPT;
+    if (m.water) {
     hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
-    uint32_t stage = ST_APPROX;             /* k_step_begin opens the first attempt */
+    stage = ST_APPROX;                      /* k_step_begin opens the first attempt */
     uint64_t before[8], atStart[8];
     std::memcpy(before, mirror_.counters, sizeof(before));
     std::memcpy(atStart, mirror_.counters, sizeof(atStart));
@@ -1694,15 +1918,18 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* one approximation's worth of guarded kernels */
     auto enqueue_batch = [&](bool withHead, bool withTail) {
         if (withHead) {
-            if (multi && fusedMulti) timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props<2>, grid, block, 0, st, v); });
-            else timed(KID_PROPS, [&] { hipLaunchKernelGGL(k_props<0>, grid, block, 0, st, v); });
+            if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
+            else if (multi && fusedMulti) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); });
+            else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), grid, block, 0, st, v); });
             if (multi && !fusedMulti) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
-            if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
+            else if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
-                timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
@@ -1722,9 +1949,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             hipLaunchKernelGGL(k_decide_balance, one, block, 0, st, v);
         }
         if (withTail) {     /* restore-best and the flow sums of the accepted step: once per poll group */
-            if (I.useFused) timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore<true>, grid, block, 0, st, v); });
+            if (heatOn && I.useFused) timed(KID_RESTORE, [&] { hipLaunchKernelGGL((k_restore<true, true>), grid, block, 0, st, v); });
+            else if (I.useFused) timed(KID_RESTORE, [&] { hipLaunchKernelGGL((k_restore<true, false>), grid, block, 0, st, v); });
             else {
-                timed(KID_RESTORE, [&] { hipLaunchKernelGGL(k_restore<false>, grid, block, 0, st, v); });
+                timed(KID_RESTORE, [&] { if (heatOn) hipLaunchKernelGGL((k_restore<false, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_restore<false, false>), grid, block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
             }
             timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, grid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, grid, block, 0, st, v); });
@@ -1798,6 +2026,38 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     {   /* approximations this step took (rejected attempts included) = batches the next one will queue up front */
         const uint64_t used = I.hostCtrl->counters[2] - atStart[2];
         I.lastBatches = used < 1 ? 1u : (uint32_t)used;
+    }
+    }   /* if (m.water) */
+
+    if (heatOn && stage == ST_ACCEPT) {
+        /* heat part of computeStep (soilFluxes3D.cpp:1802-1818): every kernel is guarded by Ctrl::hStage; one batch =
+         * boundary, node properties, rows, a run of sweeps, balance, flux bookkeeping; polled once per batch */
+        hipLaunchKernelGGL(k_heat_begin, one, one, 0, st, v.ctrl, maxTimeStep, m.water ? 1 : 0);
+        hipLaunchKernelGGL(k_heat_save_water, grid, block, 0, st, v);
+        int hguard = 0;
+        while (true) {
+            hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
+            hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
+            hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
+            uint32_t chunk = I.lastHeatSweeps + 2;
+            if (chunk < 4) chunk = 4;
+            if (chunk > 64) chunk = 64;
+            for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
+            hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
+            if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const Ctrl& c = *I.hostCtrl;
+            if (c.hSweepsLast > 0) I.lastHeatSweeps = c.hSweepsLast;
+            if (c.hStage == HS_FINISHED) break;
+            if (c.hStage == HS_IDLE) { snprintf(err_, sizeof(err_), "heat step did not start (water stage %u)", c.stage); stage = ST_FAIL; break; }
+            if (++hguard > 1000000) { snprintf(err_, sizeof(err_), "heat state machine did not terminate (stage %u)", c.hStage); return SF3D_SOLVER_ERROR; }
+        }
+        m.hostStaleHeat = true;
+    } else if (!m.water) {
+        HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     mirror_ = *I.hostCtrl;
     if (mirror_.distError) snprintf(err_, sizeof(err_), "rank %d: a peer did not answer within the bounded wait (multi-GPU exchange)", rank_);
