@@ -2050,10 +2050,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             HIP_TRY(hipStreamSynchronize(st));
             const Ctrl& c = *I.hostCtrl;
             if (c.hSweepsLast > 0) I.lastHeatSweeps = c.hSweepsLast;
+            if (getenv("SF3D_HEAT_DEBUG") && getenv("SF3D_HEAT_DEBUG")[0] == '2') fprintf(stderr, "gpu heatLoop stage %u next dt %g outer %g/%g sweeps %u MBR %.6e storage %.12e sink %.6e courant %.6e\n", c.hStage, c.hDt, c.hOuterDt, c.hOuterSum, c.hSweepsLast, c.heatCur.MBR, c.heatCur.storage, c.heatCur.sinkSource, c.hCourant);
             if (c.hStage == HS_FINISHED) break;
             if (c.hStage == HS_IDLE) { snprintf(err_, sizeof(err_), "heat step did not start (water stage %u)", c.stage); stage = ST_FAIL; break; }
             if (++hguard > 1000000) { snprintf(err_, sizeof(err_), "heat state machine did not terminate (stage %u)", c.hStage); return SF3D_SOLVER_ERROR; }
         }
+        if (getenv("SF3D_HEAT_DEBUG")) fprintf(stderr, "heat: water dt %g: %u heat steps accepted, %u halved, last dt %g, last sweeps %u, courant %g, MBR %g\n", I.hostCtrl->dtWater, I.hostCtrl->hRows, I.hostCtrl->hPad, I.hostCtrl->hDt, I.hostCtrl->hSweepsLast, I.hostCtrl->hCourant, I.hostCtrl->heatCur.MBR);
         m.hostStaleHeat = true;
     } else if (!m.water) {
         HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));

@@ -1,0 +1,74 @@
+"""Coupled heat transport (BASELINE config 5): the HIP product against the CPU oracle, live, at
+sizes the golden vectors do not cover - a 64x64x8 heterogeneous catchment and the Ravone DEM window (irregular
+graph, holes, short columns) with every top soil cell an atmosphere boundary.  Tolerance 1e-6 relative on node
+temperature and total potential, identical accepted-dt sequences."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from criteria3d_amd import capi, catchment as cm
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def rel(a, b, floor=1e-9):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def run_both(product, oracle, m, heat, rains, max_steps=None):
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        # one oracle thread: with several, the reference's own boundary loop races where a HeatSurface node writes the
+        # evaporation of ponded water into its surface node (water.cpp:729-732, inside an OpenMP for); the serial order
+        # is the defined behaviour and the one the golden vectors pin
+        cm.build(sf, m, threads=1, heat=heat)
+    soil = slice(m.ns, m.n)
+    for h, mm in enumerate(rains):
+        res = []
+        for sf in (product, oracle):
+            cm.apply_heat_forcing(sf, m, h)
+            steps, dts = cm.run_hour(sf, m, mm, max_steps=max_steps)
+            res.append((dts, sf.temperature(0, m.n)[soil], sf.total_potential(0, m.n), sf.boundary_water_flow(0, m.n)))
+        (gd, gT, gH, gB), (od, oT, oH, oB) = res
+        assert len(gd) == len(od), f"hour {h}: {len(gd)} vs {len(od)} accepted steps"
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+        assert rel(gT, oT) < RTOL, f"hour {h}: T {rel(gT, oT):.2e}"
+        assert rel(gH, oH) < RTOL, f"hour {h}: H {rel(gH, oH):.2e}"
+        scale = max(np.max(np.abs(oB)), 1e-12)
+        assert np.max(np.abs(gB - oB)) <= 1e-6 * scale, f"hour {h}: boundary water flow (evaporation)"
+
+
+def test_heat_catchment_64x64x8_latent(product, oracle):
+    m = cm.with_heat_surface(cm.catchment_model(64, 64, 8, heterogeneous=True))
+    run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), [5.0, 0.0, 0.0])
+
+
+def test_heat_only_catchment(product, oracle):
+    """isComputeWater = false: pure conduction with lateral links under the diurnal atmosphere"""
+    m = cm.with_heat_surface(cm.catchment_model(48, 48, 6))
+    run_both(product, oracle, m, cm.Heat(water=False, latent=False, save_mode=1), [0.0] * 4)
+
+
+def test_heat_ravone_window(product, oracle):
+    """BASELINE config 5 in small: real terrain (72x72 window of DEM_Ravone.flt), 14 soil layers from 2 cm, coupled
+    water + heat.  The thin top layer makes the boundary Courant rule cut every water step into dozens of heat steps
+    (updateBoundaryHeatData), so only the first two water steps are run (the oracle needs ~25 s for them)."""
+    dem = np.load(Path(__file__).resolve().parent / "golden" / "ravone_dem_window_72x72.npy")
+    m = cm.with_heat_surface(cm.dem_model(dem))
+    run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), [2.0], max_steps=2)
+
+
+def test_heat_is_not_sharded_yet(product):
+    """asking for heat on a multi-rank model fails loudly instead of computing something else"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    product.check(product.lib.sf3d_reset_solver_state(), "reset")
+    product.check(product.lib.sf3d_dist_prepare(0, 2), "dist_prepare")
+    try:
+        with pytest.raises(capi.SF3DError):
+            cm.build(product, m, heat=cm.Heat())
+    finally:
+        product.lib.sf3d_clean()
+        product.check(product.lib.sf3d_dist_prepare(0, 1), "dist_prepare")
