@@ -1576,7 +1576,6 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         v.cdesc = dcdesc;
 
         if (m.heat) {       /* coupled heat transport: state, system, per-node conductivities, boundary and link flux arrays */
-            if (world_ > 1) { snprintf(err_, sizeof(err_), "heat transport is not sharded across GPUs yet (isComputeHeat with %d ranks)", world_); return SF3D_PARAMETER_ERROR; }
             HeatDev& hv = v.heat;
             hv = HeatDev{};
             hv.on = 1; hv.water = m.water ? 1u : 0u; hv.vapor = m.heatVapor ? 1u : 0u; hv.advection = m.heatAdvection ? 1u : 0u;
@@ -1884,6 +1883,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool multi = world_ > 1;
     const bool heatOn = v.heat.on != 0;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
+    if (heatOn && multi) I.useFused = 1;       /* the sharded heat step exists only in the fused-exchange form */
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
@@ -1918,7 +1918,11 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* one approximation's worth of guarded kernels */
     auto enqueue_batch = [&](bool withHead, bool withTail) {
         if (withHead) {
-            if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
+            if (heatOn && multi) {      /* sharded heat always uses the fused exchange; halo conductivities are recomputed locally */
+                timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, true>), grid, block, 0, st, v); });
+                hipLaunchKernelGGL(k_heat_halo_water, pgrid, block, 0, st, v);
+            }
+            else if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
             else if (multi && fusedMulti) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); });
             else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), grid, block, 0, st, v); });
             if (multi && !fusedMulti) {

@@ -27,21 +27,28 @@ elif case == "het":
     m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
 elif case == "ragged":
     m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
+elif case == "heat":
+    m, plan = cm.with_heat_surface(cm.catchment_model(40, 48, 6, heterogeneous=True)), [4.0, 0.0]
 else:
     raise SystemExit("unknown case")
+heat = cm.Heat(water=True, latent=True, save_mode=0) if case == "heat" else None
 # a throw-away model first: re-initialisation must drop the windows, re-export and re-connect
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-cm.build(sf, m, threads=1, dist=(rank, world, allgather))
+cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
 cm.run_hour(sf, m, 5.0, max_steps=2)
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-cm.build(sf, m, threads=1, dist=(rank, world, allgather))
+cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
 owner = sf.owner_map(world, m.n)
 res = {"owner": owner}
 t0 = time.time()
 for h, item in enumerate(plan):
     mm, mx = item if isinstance(item, tuple) else (item, None)
+    if heat is not None:
+        cm.apply_heat_forcing(sf, m, h)
     steps, dts = cm.run_hour(sf, m, mm, max_steps=mx)
     s = cm.snapshot(sf, m)
+    if heat is not None:
+        res[f"T_h{h}"] = sf.temperature(0, m.n)
     res[f"dts_h{h}"] = np.array(dts)
     res[f"H_h{h}"] = s["H"]; res[f"Se_h{h}"] = s["Se"]
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):

@@ -59,16 +59,3 @@ def test_heat_ravone_window(product, oracle):
     dem = np.load(Path(__file__).resolve().parent / "golden" / "ravone_dem_window_72x72.npy")
     m = cm.with_heat_surface(cm.dem_model(dem))
     run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), [2.0], max_steps=2)
-
-
-def test_heat_is_not_sharded_yet(product):
-    """asking for heat on a multi-rank model fails loudly instead of computing something else"""
-    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
-    product.check(product.lib.sf3d_reset_solver_state(), "reset")
-    product.check(product.lib.sf3d_dist_prepare(0, 2), "dist_prepare")
-    try:
-        with pytest.raises(capi.SF3DError):
-            cm.build(product, m, heat=cm.Heat())
-    finally:
-        product.lib.sf3d_clean()
-        product.check(product.lib.sf3d_dist_prepare(0, 1), "dist_prepare")

@@ -75,3 +75,26 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
             tot = sum(float(res[f"{k}_h{h}"]) for res in ranks)
             assert abs(tot - snap[k]) <= RTOL * max(abs(snap[k]), 1e-3), (k, tot, snap[k])
     assert all((res["counters"] == ranks[0]["counters"]).all() for res in ranks)
+
+
+@pytest.mark.parametrize("world,port", [(2, 29621), (3, 29622)])
+def test_sharded_heat_matches_oracle(oracle, tmp_path, world, port):
+    """coupled water + heat (latent heat, atmosphere boundary on every column) sharded by row strips: halo temperatures
+    travel with every heat sweep, halo conductivities are recomputed locally, decisions are all-gathered"""
+    ranks = run_ranks(world, "heat", tmp_path, port)
+    m = cm.with_heat_surface(cm.catchment_model(40, 48, 6, heterogeneous=True))
+    oracle.lib.sf3d_reset_solver_state()
+    cm.build(oracle, m, threads=1, heat=cm.Heat(water=True, latent=True, save_mode=0))
+    owner = ranks[0]["owner"]
+    soil = np.arange(m.n) >= m.ns
+    for h, mm in enumerate([4.0, 0.0]):
+        cm.apply_heat_forcing(oracle, m, h)
+        _, dts = cm.run_hour(oracle, m, mm)
+        To, Ho = oracle.temperature(0, m.n), oracle.total_potential(0, m.n)
+        T = np.empty(m.n); H = np.empty(m.n)
+        for r, res in enumerate(ranks):
+            mine = owner == r
+            T[mine] = res[f"T_h{h}"][mine]; H[mine] = res[f"H_h{h}"][mine]
+            np.testing.assert_allclose(res[f"dts_h{h}"], dts, rtol=1e-12)
+        assert np.max(np.abs(T[soil] - To[soil]) / To[soil]) < RTOL
+        assert np.max(np.abs(H - Ho) / np.maximum(np.abs(Ho), 1e-9)) < RTOL
