@@ -33,7 +33,8 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
-             "C5S": (519, 1208, 15)}      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
+             "C5S": (519, 1208, 15),      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
+             "C5": (519, 1208, 15)}       # the Ravone DEM itself (tests/golden/DEM_Ravone.flt, 422 282 valid cells of 4 m)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
 ALGO_BYTES = {"k_sweep": 152, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
@@ -43,12 +44,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None):
+def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, heat=None):
     """Run `hours` simulated hours; return wall seconds spent inside the computeStep loops."""
     total = 0.0
     for h in range(hours):
         mm = cm.FORCINGS[forcing](h)
         sf.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(mm, model.cell_area)))
+        if heat is not None:
+            cm.apply_heat_forcing(sf, model, h)                     # hourly atmosphere at the HeatSurface nodes
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")          # inputs resident before the clock starts
         t0 = time.perf_counter()
         if hour_starts is not None:
@@ -119,6 +122,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6, help="timed simulated hours")
     ap.add_argument("--warmup", type=int, default=1, help="warm-up simulated hours (discarded)")
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--heat", action="store_true", help="coupled heat transport (latent heat, atmosphere boundary on every top soil cell)")
     ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
@@ -171,19 +175,29 @@ def main():
 
     nx, ny, nz = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    model = cm.dem_model_fast(cm.synthetic_dem(ny, nx)) if args.workload == "C5S" else cm.catchment_model(nx, ny, nz)
+    if args.workload == "C5S":
+        model = cm.dem_model_fast(cm.synthetic_dem(ny, nx))
+    elif args.workload == "C5":
+        from criteria3d_amd import esri
+        model = cm.dem_model_fast(esri.read_grid(ROOT / "tests" / "golden" / "DEM_Ravone.flt")[0])
+    else:
+        model = cm.catchment_model(nx, ny, nz)
+    heat = None
+    if args.heat:
+        model = cm.with_heat_surface(model)
+        heat = cm.Heat(water=True, latent=True, save_mode=0)
     log(f"[bench] rank {rank}: {args.workload} model arrays in {time.perf_counter() - t0:.1f}s ({model.n} nodes)")
 
     def fresh():
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, model, threads=1, dist=shard)
+        cm.build(sf, model, threads=1, dist=shard, heat=heat)
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
 
     t0 = time.perf_counter()
     fresh()
     log(f"[bench] rank {rank}: graph build + upload in {time.perf_counter() - t0:.1f}s")
     if args.warmup > 0:
-        run_hours(sf, cm, model, args.forcing, args.warmup)
+        run_hours(sf, cm, model, args.forcing, args.warmup, heat=heat)
         fresh()
 
     # HIP events around the dominant kernel only, on every 4th computeStep (mode 2); --time-all-kernels
@@ -193,7 +207,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     c0 = sf.counters()
-    elapsed = run_hours(sf, cm, model, args.forcing, args.steps, per_step=per_step, hour_starts=hour_starts)
+    elapsed = run_hours(sf, cm, model, args.forcing, args.steps, per_step=per_step, hour_starts=hour_starts, heat=heat)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -201,6 +215,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     c1 = sf.counters()
+    tw = sf.lib.sf3d_get_total_water_content()
+    if not np.isfinite(tw):     # computeStep keeps returning a dt after stepNan, like the reference: such a run measures nothing
+        raise RuntimeError(f"rank {rank}: the state is not finite after the timed steps (total water content {tw}): invalid run")
     stats = sf.kernel_stats()
     sf.lib.sf3d_kernel_timing(0)
 
@@ -237,7 +254,7 @@ def main():
                                     "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
                                 for k, v in stats.items()}}
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.heat:      # the baseline leg drives the water-only set-up
         try:
             cpu = cpu_baseline(cm, capi, model, args.forcing, args.workload,
                                (hour_starts[0], per_step) if hour_starts else None, budget_s=args.cpu_budget,
@@ -258,7 +275,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ("synthetic Ravone-like DEM (irregular)" if args.workload == "C5S" else "tilted-plane catchment (SURVEY.md 8d)") + f", forcing {args.forcing}, "
+        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone DEM (DATA/DEM/DEM_Ravone.flt), 14 soil layers to 0.95 m"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + f", forcing {args.forcing}, "
                                f"{args.steps} simulated hours from the initial state",
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},

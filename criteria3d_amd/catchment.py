@@ -508,7 +508,7 @@ def dem_model(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, depth
                  link_node=np.array(ln, np.uint32), link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8),
                  link_area=np.array(la), soil_index=soil_index, soils=soils, psi0_soil=-3.0, lv_ratio=lv_ratio,
                  numerics=(dtmin, 3600.0, 150, 10, 9, 2), cell_area=area, shape=(nx, ny, nz),
-                 meta=dict(kind="dem", layers=thick))
+                 meta=dict(kind="dem", layers=thick, index=index, cell=cell))
 
 
 def dem_model_fast(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, depth: float = 0.95,
@@ -587,7 +587,7 @@ def dem_model_fast(dem: np.ndarray, cell: float = 4.0, nodata: float = -9999.0, 
                  link_to=cand_to[mask].astype(np.uint32), link_dir=cand_dir[mask], link_area=cand_area[mask],
                  soil_index=soil_index, soils=soils, psi0_soil=-3.0, lv_ratio=lv_ratio,
                  numerics=(min(6.0, cell / 20.0), 3600.0, 150, 10, 9, 2), cell_area=area, shape=(nx, ny, nz),
-                 meta=dict(kind="dem", layers=list(thick)))
+                 meta=dict(kind="dem", layers=list(thick), index=index, cell=cell))
 
 
 def synthetic_dem(ny: int = 1208, nx: int = 519, seed: int = 2021, nodata: float = -9999.0) -> np.ndarray:

@@ -1253,6 +1253,7 @@ struct DeviceSolver::Impl {
     uint32_t lastSweeps = 8;
     uint32_t lastBatches = 1;
     uint32_t lastHeatSweeps = 8;
+    uint32_t lastHeatSteps = 1;            /* heat steps (accepted + halved) of the previous computeStep: look-ahead depth */
     double* heatOut[6] = {nullptr};       /* bAero, bSoilCond, bSens, bLat, bRad, bAdv (device) */
     /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
@@ -2039,7 +2040,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         hipLaunchKernelGGL(k_heat_begin, one, one, 0, st, v.ctrl, maxTimeStep, m.water ? 1 : 0);
         hipLaunchKernelGGL(k_heat_save_water, grid, block, 0, st, v);
         int hguard = 0;
+        uint32_t lookH = I.lastHeatSteps < 1 ? 1 : (I.lastHeatSteps > 8 ? 8 : I.lastHeatSteps);
         while (true) {
+            for (uint32_t bq = 0; bq < lookH; ++bq) {      /* look-ahead: as many guarded heat steps per poll as the last computeStep needed (<= 8) */
             hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
             hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
             hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
@@ -2049,13 +2052,14 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
             hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
             if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
+            }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const Ctrl& c = *I.hostCtrl;
             if (c.hSweepsLast > 0) I.lastHeatSweeps = c.hSweepsLast;
             if (getenv("SF3D_HEAT_DEBUG") && getenv("SF3D_HEAT_DEBUG")[0] == '2') fprintf(stderr, "gpu heatLoop stage %u next dt %g outer %g/%g sweeps %u MBR %.6e storage %.12e sink %.6e courant %.6e\n", c.hStage, c.hDt, c.hOuterDt, c.hOuterSum, c.hSweepsLast, c.heatCur.MBR, c.heatCur.storage, c.heatCur.sinkSource, c.hCourant);
-            if (c.hStage == HS_FINISHED) break;
+            if (c.hStage == HS_FINISHED) { I.lastHeatSteps = c.hRows + c.hPad; break; }
             if (c.hStage == HS_IDLE) { snprintf(err_, sizeof(err_), "heat step did not start (water stage %u)", c.stage); stage = ST_FAIL; break; }
             if (++hguard > 1000000) { snprintf(err_, sizeof(err_), "heat state machine did not terminate (stage %u)", c.hStage); return SF3D_SOLVER_ERROR; }
         }
