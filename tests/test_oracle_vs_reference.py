@@ -13,7 +13,8 @@ from tests.scenarios import run_scenario
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("name", ["c1_column", "ragged_edge_cases", "ragged_arithmetic_vg", "ragged_geometric", "het_patches"])
+@pytest.mark.parametrize("name", ["c1_column", "ragged_edge_cases", "ragged_arithmetic_vg", "ragged_geometric", "het_patches",
+                                  "heat_column_latent", "heat_column_conduction"])
 def test_bitwise_equal(name):
     p = subprocess.run([sys.executable, str(ROOT / "tests" / "live_compare.py"), name], capture_output=True, text=True)
     if p.returncode == 77:
