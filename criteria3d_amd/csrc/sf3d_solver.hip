@@ -1588,7 +1588,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             HIP_TRY(alloc0(hv.heatFlux, N)); HIP_TRY(alloc0(hv.invariant, N));
             HIP_TRY(alloc0(hv.hC, N)); HIP_TRY(alloc0(hv.hcapTerm, N)); HIP_TRY(alloc0(hv.hb, N)); HIP_TRY(alloc0(hv.hD, N));
             HIP_TRY(dev_alloc(I.allocs, hv.hA2, NS / 2)); HIP_TRY(hipMemset(hv.hA2, 0, NS * 8));
-            HIP_TRY(alloc0(hv.kHeat, N)); HIP_TRY(alloc0(hv.kIsoVap, N));
+            HIP_TRY(alloc0(hv.kHeat, N)); HIP_TRY(alloc0(hv.kIsoVap, N)); HIP_TRY(alloc0(hv.hAvg, N));
             HIP_TRY(alloc0(hv.wThLiq, N)); HIP_TRY(alloc0(hv.wThVap, N)); HIP_TRY(alloc0(hv.wTm, N));
             const double** inputs[9] = {&hv.bHeightWind, &hv.bHeightT, &hv.bRoughH, &hv.bT, &hv.bRH, &hv.bWind, &hv.bNetIrr, &hv.bFixT, &hv.bFixDepth};
             for (auto* pp : inputs) { HIP_TRY(alloc0(tmp, N)); *pp = tmp; }
