@@ -1481,6 +1481,34 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             v.world = world_; v.rank = rank_;
         }
         listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
+        {   /* XCD banding.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and walks the list in groups of four
+             * chunks, so list group g is processed by XCD g % 8: consecutive groups land on different XCDs and every XCD's
+             * L2 fetches the x values of the rows above and below its own.  Within each block of P chunks - P = the
+             * vertical period of the numbering (one layer of a layer-major grid) - the groups are transposed (P/32 x 8) so
+             * that XCD k gets the contiguous band k of every layer: lateral and vertical neighbours then sit in the same
+             * L2.  Any order of the list is valid; this one only applies when the numbering has such a period. */
+            const char* e = getenv("SF3D_XCD_BANDS");
+            const bool want = e ? (e[0] != '0') : false;
+            uint32_t P = 0;
+            if (want && nChunks > 0) {
+                std::vector<int64_t> deltas;
+                for (uint32_t q = v.qSplit; q < nChunks; q += (nChunks / 64 + 1)) if (cdesc[q].kind[1] == LK_SOIL_VERT) deltas.push_back(cdesc[q].delta[1]);
+                if (!deltas.empty()) {
+                    std::sort(deltas.begin(), deltas.end());
+                    const int64_t d = deltas[deltas.size() / 2];
+                    if (d > 0 && d % (SF3D_CHUNK * 32) == 0) P = (uint32_t)(d / SF3D_CHUNK);
+                }
+            }
+            if (P >= 256 && v.nListSurf % 32 == 0) {
+                const uint32_t per = SF3D_BLOCK / SF3D_CHUNK, groupsPerLayer = P / per, band = groupsPerLayer / 8;
+                std::vector<uint32_t> src(listSurf);
+                for (size_t base = 0; base + P <= src.size(); base += P)
+                    for (uint32_t k = 0; k < 8; ++k)
+                        for (uint32_t r = 0; r < band; ++r)
+                            for (uint32_t w = 0; w < per; ++w)
+                                listSurf[base + (size_t)(8 * r + k) * per + w] = src[base + (size_t)(band * k + r) * per + w];
+            }
+        }
 
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness, *larea, *ldist;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
