@@ -16,7 +16,10 @@
  *   linear system  A2[5][N] row-normalised off-diagonals (static ELL, zeros kept; slots paired so
  *                  every access is 16 B per lane), b
  *   control block  Ctrl: solver parameters, adaptive dt, stage of the step state machine,
- *                  balances, counters - decisions are taken on the device by 1-block kernels
+ *                  balances, counters - decisions are taken on the device, by the block of the producing
+ *                  kernel that arrives last (or by 1-block kernels with SF3D_FUSED_DECIDE=0)
+ *   heat           HeatDev (coupled heat transport, sf3d_heat.inc): temperature pool TX[3][N], heat system
+ *                  hA2[5][N]/hD/hb, per-node conductivities, boundary and link-flux arrays
  */
 #ifndef SF3D_DEVICE_H
 #define SF3D_DEVICE_H
