@@ -77,6 +77,27 @@ def build_v1_alias(force: bool = False) -> Path:
     return V1_LIB
 
 
+REFERENCE = Path("/root/reference")
+
+
+def build_v2_demo(force: bool = False) -> Path:
+    """tests/v2_caller_demo.cpp: a C++ caller of the soilFluxes3D::v2 API linked against the shim.  With the reference
+    mounted it is compiled against the reference's OWN soilFluxes3D.h (the caller-side header of bin/CRITERIA3D);
+    elsewhere (GPU box) the prebuilt binary is used, or shim/soilFluxes3D_api.h if it has to be rebuilt."""
+    demo = ROOT / "shim" / "v2_caller_demo"
+    dsrc = ROOT / "tests" / "v2_caller_demo.cpp"
+    build_shim()
+    if force or _stale(demo, [dsrc, SHIM_LIB]):
+        ref_inc = REFERENCE / "agrolib" / "soilFluxes3D"
+        if (ref_inc / "soilFluxes3D.h").exists():
+            inc = ["-DSF3D_USE_REFERENCE_HEADER", f"-I{ref_inc}", f"-I{REFERENCE / 'agrolib' / 'mathFunctions'}"]
+        else:
+            inc = [f"-I{ROOT / 'shim'}"]
+        _run(["g++", "-std=c++17", "-O2", *inc, str(dsrc), "-o", str(demo), f"-L{ROOT / 'shim'}", "-lsoilFluxes3D_mi355x",
+              f"-L{CSRC}", "-lsf3d_hip", f"-Wl,-rpath,{ROOT / 'shim'}", f"-Wl,-rpath,{CSRC}"])
+    return demo
+
+
 def build_oracle(with_reference: bool = True) -> None:
     """Test infrastructure: the CPU restatement and (when /root/reference is present) oracle/_ref."""
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
@@ -88,4 +109,5 @@ def build_all(force: bool = False) -> None:
     build_product(force)
     build_shim(force)
     build_v1_alias(force)
+    build_v2_demo(force)
     build_oracle()
