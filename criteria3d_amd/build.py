@@ -103,6 +103,7 @@ def build_oracle(with_reference: bool = True) -> None:
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
     if with_reference:
         _run(["make", "-C", str(ROOT / "oracle"), "ref"])
+        _run(["make", "-C", str(ROOT / "oracle"), "ref-tuned"])
 
 
 def build_all(force: bool = False) -> None:

@@ -336,3 +336,10 @@ def load_reference() -> SF3D:
     if QT_CORE.exists():
         C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)   # linked by soname, deliberately not on the rpath
     return SF3D(REFERENCE_LIB)
+
+
+def load_reference_tuned() -> SF3D:
+    """The same unmodified sources built -O3 -march=x86-64-v3 (oracle/Makefile `ref-tuned`): CPU baseline timing only."""
+    if QT_CORE.exists():
+        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)
+    return SF3D(REFERENCE_LIB.with_name("libsf3d_ref_tuned.so"))

@@ -12,7 +12,7 @@ sys.path.insert(0, %r)
 import numpy as np
 from criteria3d_amd import capi, catchment as cm
 backend, nx, ny, nz, forcing, hours, threads, budget = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]), int(sys.argv[7]), float(sys.argv[8])
-sf = capi.load_reference() if backend == "reference" else capi.load_oracle()
+sf = {"reference": capi.load_reference, "reference_tuned": capi.load_reference_tuned, "oracle": capi.load_oracle}[backend]()
 m = cm.catchment_model(nx, ny, nz)
 cm.build(sf, m, threads=threads)
 used = int(sf.lib.sf3d_set_threads_number(threads))
@@ -41,12 +41,13 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/cpu_baselines.json"
     ncpu = os.cpu_count() or 1
     res = {"host_threads": ncpu, "cpu_model": next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "runs": []}
-    for backend in ("reference",):
-        for threads in (1, 16, 64, ncpu):
+    quick = len(sys.argv) > 2 and sys.argv[2] == "tuned"     # only the -O3 -march=x86-64-v3 build next to the project-flags build
+    for backend in (("reference", "reference_tuned") if quick else ("reference",)):
+        for threads in ((1, 16) if quick else (1, 16, 64, ncpu)):
             res["runs"].append(run(backend, (64, 64, 10), "F20", 6, threads))
-        for threads in (16, 64, ncpu):
+        for threads in ((16,) if quick else (16, 64, ncpu)):
             res["runs"].append(run(backend, (256, 256, 15), "F20", 2, threads, budget=40.0))
-        for threads in (32, 64, ncpu):
+        for threads in ((32,) if quick else (32, 64, ncpu)):
             res["runs"].append(run(backend, (512, 512, 20), "F20", 1, threads, budget=25.0))
     json.dump(res, open(out, "w"), indent=1)
     for r in res["runs"]:
