@@ -121,3 +121,22 @@ def test_cxx_caller_through_the_v2_symbols(oracle):
             assert abs(float(v[k]) - e) <= RTOL * max(abs(e), 1e-9), (h, k, v[k], e)
         ef = L.sf3d_get_node_heat_max_flux(2, capi.LINK_DOWN, 0)
         assert abs(float(v["flux"]) - ef) <= 2e-6 * max(abs(ef), 1e-9), (h, v["flux"], ef)
+
+
+def test_heat_large_grid_properties(product):
+    """size-independent properties at 256x256x8 (0.52 M nodes, no oracle run needed): pure conduction closes its own
+    energy balance (whole-period heat MBR of computePeriod) and the run is bit-reproducible."""
+    m = cm.with_heat_surface(cm.catchment_model(256, 256, 8))
+    heat = cm.Heat(water=False, latent=False, save_mode=0)
+    runs = []
+    for rep in range(2):
+        product.check(product.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(product, m, heat=heat)
+        for h in range(2):
+            cm.apply_heat_forcing(product, m, h + 10)            # daytime atmosphere: net heating
+            product.lib.sf3d_compute_period(3600.0)
+        T = product.temperature(0, m.n)[m.ns:]
+        runs.append((T, product.lib.sf3d_get_heat_mbr(), product.lib.sf3d_get_heat_mbe()))
+    assert np.all(np.isfinite(runs[0][0])) and 270.0 < runs[0][0].min() and runs[0][0].max() < 320.0
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]        # bit-reproducible
+    assert abs(runs[0][1]) < 2e-2, runs[0][1]       # conduction with the theta-weighted scheme: the balance closes to ~1 %
