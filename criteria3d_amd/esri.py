@@ -91,8 +91,9 @@ def save_water_state(sf: capi.SF3D, m, directory, hdr: dict | None = None, nodat
 def load_water_state(sf: capi.SF3D, m, directory, restore_time_step: bool = True):
     """loadWaterPotentialState: every WP_<cm>.flt found is a depth level; each model layer takes the level of its own
     depth or, between two levels, the mix the reference computes - with its integer division
-    `w0 = (currentDepthCm - depthList[layer0]) / delta` (criteria3DProject.cpp:3039-3043), i.e. the upper level
-    unless the layer sits exactly on the lower one; cells without data take the first valid level above.
+    `w0 = (currentDepthCm - depthList[layer0]) / delta` (criteria3DProject.cpp:3039-3043): w0 = 0 and w1 = 1 for a layer
+    strictly between two levels, i.e. the deeper level's value (the upper one where the deeper holds NODATA); cells whose
+    upper level holds NODATA take the first valid level above.
     Ends with initializeBalance-free state (call sf3d_initialize_balance afterwards, as the application does)."""
     water = Path(directory) / "water"
     levels = {}

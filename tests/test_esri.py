@@ -55,3 +55,41 @@ def test_water_state_directory_round_trip(oracle, tmp_path):
     # the setter stores z + psi: compare through the same float32 rounding the files impose
     assert np.allclose(back, psi.astype(np.float32).astype(np.float64), rtol=0, atol=1e-9)
     assert oracle.lib.sf3d_get_time_step() == dt
+
+
+def test_load_from_coarser_levels_follows_the_reference_rule(oracle, tmp_path):
+    """a state directory with fewer depth levels than the model has layers (as written by a run with other layering):
+    loadWaterPotentialState takes, for a layer between two levels, w0 = (depth - upper) / delta in INTEGER arithmetic
+    (criteria3DProject.cpp:3039-3043): w0 = 0, w1 = 1, so the layer takes the DEEPER level's value - and for a cell
+    whose level holds NODATA the first valid level above"""
+    dem, hdr = esri.read_grid(GOLDEN / "DEM_Ravone.flt")
+    m = cm.dem_model(dem[48:60, 444:456])
+    oracle.lib.sf3d_reset_solver_state()
+    cm.build(oracle, m)
+    index = m.meta["index"]
+    depths_cm = [int(round(d * 100)) for d in esri.layer_depths(m)]
+    water = tmp_path / "state" / "water"
+    water.mkdir(parents=True)
+    levels = {0: 0.0, depths_cm[3]: -1.5, depths_cm[8]: -2.5}
+    for cmv, val in levels.items():
+        g = np.full(index.shape[1:], val, np.float32)
+        if cmv == depths_cm[8]:
+            g[0, 0] = -9999.0                                   # a hole in the deepest level
+        esri.write_grid(water / f"WP_{cmv}", g, dict(hdr, nodata=-9999.0))
+    found = esri.load_water_state(oracle, m, tmp_path / "state", restore_time_step=False)
+    assert found == sorted(levels)
+    psi = oracle.total_potential(0, m.n) - m.z
+    def layer_values(l):
+        ok = index[l] >= 0
+        return psi[index[l][ok]], ok
+    v, _ = layer_values(0); assert np.allclose(v, 0.0, atol=1e-12)
+    v, _ = layer_values(3); assert np.allclose(v, -1.5, atol=1e-6)
+    v, _ = layer_values(1); assert np.allclose(v, -1.5, atol=1e-6)        # between level 0 and level 3: w0 = 0, w1 = 1 -> the deeper level
+    v, ok5 = layer_values(5)                                              # between level 3 and level 8: the deeper level, except its hole
+    for (r, c), val in zip(np.argwhere(ok5), v):
+        assert abs(val - (-1.5 if (r, c) == (0, 0) else -2.5)) < 1e-6
+    deep = len(depths_cm) - 1                                            # below the last level: the last level itself
+    v, ok = layer_values(deep)
+    cells = np.argwhere(ok)
+    for (r, c), val in zip(cells, v):
+        assert abs(val - (-1.5 if (r, c) == (0, 0) else -2.5)) < 1e-6    # the hole falls back to the level above
