@@ -1079,26 +1079,32 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     if (c->stage != ST_RESTORE) return;
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
+    const uint32_t par = c->epoch & 1u;
+    const bool haloK = HEAT && FUSED && v.world > 1;      /* sharded heat: saveWaterFluxValues reads the neighbours' K */
     double st = 0., sk = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (NOT_MINE(v, i)) continue;
-        const double H = Xc[i], Ho = Xh[i], z = v.z[i];
-        double Se = 1., K = 0.;
-        if (i >= v.ns) {
-            const SoilDev s = v.soils[v.cls[i]];
-            Se = node_se(s, H, z, c->wrc);
-            K = mualem_k(s, Se, c->wrc);
-            if (HEAT && v.heat.vapor) {
-                const HeatDev& hv = v.heat;
-                const double Tm = (hv.TX[c->tCur][i] + hv.TX[c->tOld][i]) * 0.5;
-                K += h_isothermal_vapor_conductivity(s, Tm, H - z, h_theta_signed_psi(s, H - z, c->wrc)) * (H_G / H_RHOW);
+        double K = 0.;
+        if (!NOT_MINE(v, i)) {
+            const double H = Xc[i], Ho = Xh[i], z = v.z[i];
+            double Se = 1.;
+            if (i >= v.ns) {
+                const SoilDev s = v.soils[v.cls[i]];
+                Se = node_se(s, H, z, c->wrc);
+                K = mualem_k(s, Se, c->wrc);
+                if (HEAT && v.heat.vapor) {
+                    const HeatDev& hv = v.heat;
+                    const double Tm = (hv.TX[c->tCur][i] + hv.TX[c->tOld][i]) * 0.5;
+                    K += h_isothermal_vapor_conductivity(s, Tm, H - z, h_theta_signed_psi(s, H - z, c->wrc)) * (H_G / H_RHOW);
+                }
+                v.Se[i] = Se; v.K[i] = K;
             }
-            v.Se[i] = Se; v.K[i] = K;
+            boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
+            balance_terms(v, c, i, H, z, Se, st, sk);
         }
-        boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
-        balance_terms(v, c, i, H, z, Se, st, sk);
+        if (haloK) dist_put_chunk(v, q, lane_, par, 0, K);
     }
+    if (haloK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double a = block_sum(st), b = block_sum(sk);
     if (!FUSED) {
         if (threadIdx.x == 0) { v.part0[blockIdx.x] = a; v.part1[blockIdx.x] = b; }
@@ -1107,6 +1113,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     if (!arrive_last(v, a, b, true)) return;
     double vals[3] = {sum_published(v.part0, gridDim.x), sum_published(v.part1, gridDim.x), 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;
+    if (haloK) dist_unpack(v, par, 0, v.K);
     if (threadIdx.x == 0) restore_decision(v.ctrl, vals[0], vals[1]);
 }
 
