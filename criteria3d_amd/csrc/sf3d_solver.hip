@@ -2076,18 +2076,40 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         hipLaunchKernelGGL(k_heat_save_water, grid, block, 0, st, v);
         int hguard = 0;
         uint32_t lookH = I.lastHeatSteps < 1 ? 1 : (I.lastHeatSteps > 8 ? 8 : I.lastHeatSteps);
+        if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
+        /* one poll group = lookH guarded heat steps (look-ahead: as many as the last computeStep needed, <= 8), replayed
+         * from an instantiated hipGraph per shape like the water batches */
+        auto enqueue_heat = [&](uint32_t steps, uint32_t chunk) {
+            for (uint32_t bq = 0; bq < steps; ++bq) {
+                hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
+                for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
+                if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
+            }
+        };
+        auto launch_heat = [&](uint32_t steps, uint32_t chunk) -> hipError_t {
+            if (!I.useGraphs) { enqueue_heat(steps, chunk); return hipSuccess; }
+            const uint32_t key = 0x80000000u | (chunk << 8) | (steps << 1) | (v.heat.save != 0 ? 1u : 0u);
+            for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
+            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) return e;
+            enqueue_heat(steps, chunk);
+            e = hipStreamEndCapture(st, &graph);
+            if (e != hipSuccess) return e;
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (e != hipSuccess) return e;
+            I.graphs.push_back({key, exec});
+            return hipGraphLaunch(exec, st);
+        };
         while (true) {
-            for (uint32_t bq = 0; bq < lookH; ++bq) {      /* look-ahead: as many guarded heat steps per poll as the last computeStep needed (<= 8) */
-            hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
-            hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
-            hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
-            uint32_t chunk = I.lastHeatSweeps + 2;
+            uint32_t chunk = ((I.lastHeatSweeps + 2 + 3) / 4) * 4;      /* multiples of four: few graph shapes */
             if (chunk < 4) chunk = 4;
             if (chunk > 64) chunk = 64;
-            for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
-            hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
-            if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
-            }
+            HIP_TRY(launch_heat(lookH, chunk));
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
