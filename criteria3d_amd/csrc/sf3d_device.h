@@ -114,6 +114,7 @@ struct Ctrl {
     double hOuterDt, hOuterSum;   /* dtHeat / dtHeatSum of computeStep's loop                            */
     double hMaxStep, hDt, hDone;  /* maxTimeStep / dtHeat / sumHeatTime of CPUSolver::run(Heat)          */
     double hCourant, hNorm;
+    unsigned long long hNormBits;   /* running maximum of |dx| of a Gauss-Seidel sweep (bit pattern of a non-negative double) */
     HeatBalanceDev heatCur, heatPrev;
     double heatPeriodSink;    /* balanceDataCurrentPeriod.heatSinkSource                                 */
     /* ---- query results (getTotalWaterContent etc.) ---- */
@@ -154,6 +155,8 @@ struct DistView {
  * need; `on` = 0 leaves every pointer null */
 struct HeatDev {
     uint32_t on, water, vapor, advection, save;    /* simulationFlags_t, types.h:189-197 */
+    uint32_t gs;                                    /* 1: verification mode, the reference's serial Gauss-Seidel order (level-scheduled) */
+    const uint32_t* gsOrder;                        /* heat nodes sorted by dependency level (gs mode only) */
     double wf;                                      /* heatWeightFactor, types.h:307 */
     double* TX[3];                                  /* temperature pool: T, Told and the sweep buffers are indices (Ctrl::tCur/tOld) */
     const double* heatSink;

@@ -1260,6 +1260,7 @@ struct DeviceSolver::Impl {
     uint32_t lastSweeps = 8;
     uint32_t lastBatches = 1;
     uint32_t lastHeatSweeps = 8;
+    std::vector<uint32_t> gsLevelStart;    /* SF3D_HEAT_GS=1: level l = gsOrder[gsLevelStart[l] .. gsLevelStart[l+1]) */
     uint32_t lastHeatSteps = 1;            /* heat steps (accepted + halved) of the previous computeStep: look-ahead depth */
     double* heatOut[6] = {nullptr};       /* bAero, bSoilCond, bSens, bLat, bRad, bAdv (device) */
     /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
@@ -1658,6 +1659,31 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                 });
                 HIP_TRY(alloc0(tmp, NS)); hv.hdist = tmp;
                 HIP_TRY(hipMemcpy(tmp, d3.data(), NS * 8, hipMemcpyHostToDevice));
+            }
+            I.gsLevelStart.clear();
+            if (const char* ge = getenv("SF3D_HEAT_GS")) if (ge[0] == '1') {
+                if (world_ > 1) { snprintf(err_, sizeof(err_), "SF3D_HEAT_GS=1 (reference-order Gauss-Seidel) is a single-GPU verification mode"); return SF3D_PARAMETER_ERROR; }
+                /* dependency levels of the serial sweep: a node waits for its linked heat nodes with a smaller index */
+                std::vector<uint32_t> level(N, 0u);
+                uint32_t maxLevel = 0;
+                for (uint32_t i = ns; i < N; ++i) {
+                    uint32_t l = 0;
+                    for (int sl = 0; sl < SF3D_SLOTS; ++sl) {
+                        const size_t e = (size_t)sl * N + i;
+                        if ((kind[e] == LK_SOIL_VERT || kind[e] == LK_SOIL_LAT) && to[e] < i && level[to[e]] + 1 > l) l = level[to[e]] + 1;
+                    }
+                    level[i] = l;
+                    if (l > maxLevel) maxLevel = l;
+                }
+                std::vector<uint32_t> start(maxLevel + 2, 0u), order(N > ns ? N - ns : 0);
+                for (uint32_t i = ns; i < N; ++i) start[level[i] + 1]++;
+                for (uint32_t l = 0; l <= maxLevel; ++l) start[l + 1] += start[l];
+                std::vector<uint32_t> pos(start.begin(), start.end() - 1);
+                for (uint32_t i = ns; i < N; ++i) order[pos[level[i]]++] = i;
+                uint32_t* dord; HIP_TRY(dev_alloc(I.allocs, dord, order.size()));
+                if (!order.empty()) HIP_TRY(hipMemcpy(dord, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+                hv.gsOrder = dord; hv.gs = 1;
+                I.gsLevelStart = start;
             }
             m.heatStateDirty = m.heatSinkDirty = m.heatBoundaryDirty = true;
             m.hostStaleHeat = false;
@@ -2076,6 +2102,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         hipLaunchKernelGGL(k_heat_save_water, grid, block, 0, st, v);
         int hguard = 0;
         uint32_t lookH = I.lastHeatSteps < 1 ? 1 : (I.lastHeatSteps > 8 ? 8 : I.lastHeatSteps);
+        if (v.heat.gs) lookH = 1;              /* one launch per dependency level: keep the queue short */
         if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
         /* one poll group = lookH guarded heat steps (look-ahead: as many as the last computeStep needed, <= 8), replayed
          * from an instantiated hipGraph per shape like the water batches */
@@ -2084,13 +2111,23 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
                 hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
                 hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
+                if (v.heat.gs) {
+                    for (uint32_t k = 0; k < chunk; ++k) {
+                        hipLaunchKernelGGL(k_heat_gs_begin, grid, block, 0, st, v);
+                        for (size_t l = 0; l + 1 < I.gsLevelStart.size(); ++l) {
+                            const uint32_t first = I.gsLevelStart[l], cnt = I.gsLevelStart[l + 1] - first;
+                            if (cnt) hipLaunchKernelGGL(k_heat_gs_level, dim3((cnt + SF3D_BLOCK - 1) / SF3D_BLOCK), block, 0, st, v, first, cnt);
+                        }
+                        hipLaunchKernelGGL(k_heat_gs_decide, one, one, 0, st, v.ctrl);
+                    }
+                } else
                 for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
                 hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
                 if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
             }
         };
         auto launch_heat = [&](uint32_t steps, uint32_t chunk) -> hipError_t {
-            if (!I.useGraphs) { enqueue_heat(steps, chunk); return hipSuccess; }
+            if (!I.useGraphs || v.heat.gs) { enqueue_heat(steps, chunk); return hipSuccess; }
             const uint32_t key = 0x80000000u | (chunk << 8) | (steps << 1) | (v.heat.save != 0 ? 1u : 0u);
             for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
             hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;

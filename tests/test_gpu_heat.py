@@ -140,3 +140,33 @@ def test_heat_large_grid_properties(product):
     assert np.all(np.isfinite(runs[0][0])) and 270.0 < runs[0][0].min() and runs[0][0].max() < 320.0
     assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]        # bit-reproducible
     assert abs(runs[0][1]) < 2e-2, runs[0][1]       # conduction with the theta-weighted scheme: the balance closes to ~1 %
+
+
+def test_reference_order_gauss_seidel_equals_jacobi(product, oracle, monkeypatch):
+    """SF3D_HEAT_GS=1 runs the heat system with the reference's own serial Gauss-Seidel order (level-scheduled, one launch
+    per dependency level).  It must agree with the oracle more tightly than the 1e-6 bar, and the default Jacobi sweep
+    must agree with it to the solver tolerance: the choice of sweep does not move the result."""
+    m = cm.with_heat_surface(cm.catchment_model(40, 40, 6, heterogeneous=True))
+    heat = cm.Heat(water=True, latent=True, save_mode=0)
+
+    def run(sf, hours=2):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=1, heat=heat)
+        out = []
+        for h in range(hours):
+            cm.apply_heat_forcing(sf, m, h)
+            _, dts = cm.run_hour(sf, m, 4.0 if h == 0 else 0.0)
+            out.append((dts, sf.temperature(0, m.n)[m.ns:], sf.total_potential(0, m.n)))
+        return out
+
+    monkeypatch.setenv("SF3D_HEAT_GS", "1")
+    gs = run(product)
+    monkeypatch.delenv("SF3D_HEAT_GS")
+    jac = run(product)
+    ref = run(oracle)
+    for (gd, gT, gH), (jd, jT, jH), (od, oT, oH) in zip(gs, jac, ref):
+        np.testing.assert_allclose(gd, od, rtol=1e-12); np.testing.assert_allclose(jd, od, rtol=1e-12)
+        print(f"GS vs oracle {rel(gT, oT):.2e}  Jacobi vs oracle {rel(jT, oT):.2e}  Jacobi vs GS {rel(jT, gT):.2e}")
+        assert rel(gT, oT) < 1e-7, rel(gT, oT)           # same sweep order as the reference: libm last-ulp differences, amplified by the scheme
+        assert rel(jT, gT) < 1e-7, rel(jT, gT)           # Jacobi vs Gauss-Seidel: both within the stopping tolerance of the solution
+        assert rel(gH, oH) < 1e-7 and rel(jH, oH) < RTOL
