@@ -208,6 +208,28 @@ def heat_catchment_latent(sf, threads=1):
                        threads, flux_nodes=(mid, mid + m.ns))
 
 
+def heat_advection_steps(sf, threads=1):
+    """advective heat flux switched on (initializeHeatFlag(All, true, true)): the reference multiplies the ROW-NORMALISED
+    water coefficient into its link water fluxes (quirk 1), the advective term is orders of magnitude too large and the
+    temperature diverges to NaN within one ordinary step - so this case takes eight computeStep(2 s) calls, where
+    everything is still finite, to pin the advective terms of the rows, of the boundaries and of the saved fluxes"""
+    m = cm.with_heat_surface(cm.catchment_model(12, 10, 5, heterogeneous=True))
+    sf.lib.sf3d_reset_solver_state()
+    cm.build(sf, m, threads=threads, heat=cm.Heat(water=True, advection=True, latent=True, save_mode=2))
+    sf.set_sink_source_bulk(0, np.full(m.ns, cm.rain_rate(5.0, m.cell_area)))
+    hs = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE)
+    nodes = (m.ns + 10 * 5 + 6, 2 * m.ns + 10 * 5 + 6)
+    out = {"dts": [], "T": [], "H": [], "boundary_advective": [], "flux": []}
+    L = sf.lib
+    for k in range(8):
+        out["dts"].append(L.sf3d_compute_step(2.0))
+        out["T"].append(sf.temperature(0, m.n)); out["H"].append(sf.total_potential(0, m.n))
+        out["boundary_advective"].append([L.sf3d_get_node_boundary_advective_flux(int(i)) for i in hs])
+        out["flux"].append([[[L.sf3d_get_node_heat_max_flux(int(i), d, t) for t in range(FLUX_TYPES)]
+                             for d in (capi.LINK_UP, capi.LINK_DOWN, capi.LINK_LATERAL)] for i in nodes])
+    return {k: np.array(v) for k, v in out.items()}
+
+
 SCENARIOS = {
     "c1_column": c1_column,
     "c1_column_period": c1_column_period,
@@ -225,6 +247,7 @@ SCENARIOS = {
     "heat_column_latent": heat_column_latent,
     "heat_column_period": heat_column_period,
     "heat_catchment_latent": heat_catchment_latent,
+    "heat_advection_steps": heat_advection_steps,
 }
 HEAT_SCENARIOS = tuple(k for k in SCENARIOS if k.startswith("heat_"))
 

