@@ -42,7 +42,8 @@ def build_product(force: bool = False) -> Path:
     srcs = [CSRC / "sf3d_solver.hip", CSRC / "sf3d_api.cpp"]
     deps = srcs + [CSRC / "sf3d_device.h", CSRC / "sf3d_model.h", INCLUDE / "sf3d.h"]
     if force or _stale(PRODUCT_LIB, deps):
-        cmd = [HIPCC, *HIP_FLAGS, f"-I{INCLUDE}", f"-I{CSRC}", "-x", "hip", *map(str, srcs), "-o", str(PRODUCT_LIB)]
+        extra = os.environ.get("SF3D_EXTRA_HIPFLAGS", "").split()      # tuning experiments, e.g. -DSF3D_PROPS_WAVES=4
+        cmd = [HIPCC, *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-x", "hip", *map(str, srcs), "-o", str(PRODUCT_LIB)]
         _run(cmd)
     return PRODUCT_LIB
 

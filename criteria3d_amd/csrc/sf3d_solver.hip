@@ -670,8 +670,11 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
 
 /* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
  * updateBoundaryWaterData (water.cpp:632-807) */
+#ifndef SF3D_PROPS_WAVES
+#define SF3D_PROPS_WAVES 4     /* 128 VGPRs, 20 B of scratch: 236 -> 214 us at C4; 5 waves (95 VGPRs, 148 B scratch) gives the same */
+#endif
 template <int MODE, bool HEAT>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_props(DevView v)
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
