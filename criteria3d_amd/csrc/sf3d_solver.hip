@@ -226,16 +226,31 @@ __device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double
     return shOk != 0;
 }
 
-/* whole block: copy field `field` of the payload every neighbour put for epoch parity `par` into dst */
+/* whole block: copy field `field` of the payload every neighbour put for epoch parity `par` into dst.
+ * Eight independent system-scope loads per thread are in flight before the first store: the payload lives in
+ * fine-grained memory (uncached reads, ~1-2 us each), and this runs in ONE block on the critical path of every sweep. */
 __device__ __forceinline__ void dist_unpack(const DevView& v, uint32_t par, int field, double* __restrict__ dst)
 {
     const DistView* d = v.dist;
+    constexpr uint32_t U = 8;
     for (int p = 0; p < v.world; ++p) {
         const uint32_t cnt = d->recvCount[p];
         if (cnt == 0) continue;
         const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * 2 + field) * cnt;
         const uint32_t* idx = d->recvIdx[p];
-        for (uint32_t k = threadIdx.x; k < cnt; k += SF3D_BLOCK) dst[idx[k]] = SYS_LOAD(&src[k]);
+        for (uint32_t k0 = threadIdx.x; k0 < cnt; k0 += SF3D_BLOCK * U) {
+            double val[U]; uint32_t id[U];
+            #pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t k = k0 + u * SF3D_BLOCK;
+                if (k < cnt) { id[u] = idx[k]; val[u] = SYS_LOAD(&src[k]); }
+            }
+            #pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t k = k0 + u * SF3D_BLOCK;
+                if (k < cnt) dst[id[u]] = val[u];
+            }
+        }
     }
 }
 
