@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 
 WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
              "C5S": (519, 1208, 15),      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
-             "C5": (519, 1208, 15)}       # the Ravone DEM itself (tests/golden/DEM_Ravone.flt, 422 282 valid cells of 4 m)
+             "C5": (519, 1208, 15)}       # the Ravone DEM itself (tests/golden/ravone_dem_519x1208.npz, 422 282 valid cells of 4 m)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
 ALGO_BYTES = {"k_sweep": 152, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
@@ -179,7 +179,7 @@ def main():
         model = cm.dem_model_fast(cm.synthetic_dem(ny, nx))
     elif args.workload == "C5":
         from criteria3d_amd import esri
-        model = cm.dem_model_fast(esri.read_grid(ROOT / "tests" / "golden" / "DEM_Ravone.flt")[0])
+        model = cm.dem_model_fast(esri.load_dem_fixture(ROOT / "tests" / "golden" / "ravone_dem_519x1208.npz")[0])
     else:
         model = cm.catchment_model(nx, ny, nz)
     heat = None

@@ -59,6 +59,16 @@ def write_grid(path, array, hdr: dict):
     a.tofile(str(base) + ".flt")
 
 
+def load_dem_fixture(path):
+    """tests/golden/ravone_dem_519x1208.npz: the values and header fields of DATA/DEM/DEM_Ravone.flt kept as a compressed
+    numpy fixture -> (float32 array, header dict as read_grid returns it)"""
+    z = np.load(path)
+    dem = z["dem"].astype(np.float32)
+    hdr = dict(ncols=dem.shape[1], nrows=dem.shape[0], xllcorner=float(z["xllcorner"]), yllcorner=float(z["yllcorner"]),
+               cellsize=float(z["cellsize"]), nodata=float(z["nodata"]), byteorder="LSBFIRST")
+    return dem, hdr
+
+
 def layer_depths(m) -> np.ndarray:
     """centre depth [m] of every layer of a DEM model; layer 0 = surface (depth 0)"""
     thick = np.asarray(m.meta["layers"], dtype=np.float64)

@@ -8,9 +8,17 @@ from pathlib import Path
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
-def test_reads_the_ravone_dem():
-    """DATA/DEM/DEM_Ravone.flt (committed as a data fixture): the figures of SURVEY.md App. D"""
-    dem, hdr = esri.read_grid(GOLDEN / "DEM_Ravone.flt")
+def _ravone(tmp_path):
+    """the Ravone DEM (values of DATA/DEM/DEM_Ravone.flt, kept as tests/golden/ravone_dem_519x1208.npz) written out as an
+    ESRI float grid and read back through the reader under test"""
+    dem, hdr = esri.load_dem_fixture(GOLDEN / "ravone_dem_519x1208.npz")
+    esri.write_grid(tmp_path / "DEM_Ravone", dem, hdr)
+    return esri.read_grid(tmp_path / "DEM_Ravone.flt")
+
+
+def test_reads_the_ravone_dem(tmp_path):
+    """the figures of SURVEY.md App. D"""
+    dem, hdr = _ravone(tmp_path)
     assert dem.shape == (1208, 519) and hdr["cellsize"] == 4.0 and hdr["nodata"] == -9999.0
     valid = dem != hdr["nodata"]
     assert valid.sum() == 422282
@@ -31,7 +39,7 @@ def test_grid_round_trip(tmp_path):
 def test_water_state_directory_round_trip(oracle, tmp_path):
     """saveSoilWaterState / loadWaterPotentialState: one WP_<cm> grid per layer, float32 matric potentials; a rebuilt
     model loaded from the directory holds exactly those values and the saved adaptive time step"""
-    dem, hdr = esri.read_grid(GOLDEN / "DEM_Ravone.flt")
+    dem, hdr = _ravone(tmp_path)
     m = cm.dem_model(dem[48:72, 444:468])
     oracle.lib.sf3d_reset_solver_state()
     cm.build(oracle, m)
@@ -62,7 +70,7 @@ def test_load_from_coarser_levels_follows_the_reference_rule(oracle, tmp_path):
     loadWaterPotentialState takes, for a layer between two levels, w0 = (depth - upper) / delta in INTEGER arithmetic
     (criteria3DProject.cpp:3039-3043): w0 = 0, w1 = 1, so the layer takes the DEEPER level's value - and for a cell
     whose level holds NODATA the first valid level above"""
-    dem, hdr = esri.read_grid(GOLDEN / "DEM_Ravone.flt")
+    dem, hdr = _ravone(tmp_path)
     m = cm.dem_model(dem[48:60, 444:456])
     oracle.lib.sf3d_reset_solver_state()
     cm.build(oracle, m)
