@@ -192,40 +192,44 @@ __device__ __forceinline__ double dtheta_dh(const SoilDev& s, double H, double H
 __device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double (&vals)[3], int op)
 {
     if (v.world <= 1) return true;
+    __shared__ double shIn[SF3D_MAX_RANKS][3];
     __shared__ double sh[3];
     __shared__ int shOk;
-    if (threadIdx.x == 0) {
-        const DistView* d = v.dist;
-        const uint32_t e = c->epoch, par = e & 1u;
-        const unsigned long long tag = (unsigned long long)e + 1ull;
+    const DistView* d = v.dist;
+    const uint32_t e = c->epoch, par = e & 1u;
+    const unsigned long long tag = (unsigned long long)e + 1ull;
+    if (threadIdx.x == 0) shOk = 1;
+    __syncthreads();
+    if ((int)threadIdx.x < v.world) {            /* thread p talks to rank p: the stores and the waits of all peers overlap */
+        const int p = threadIdx.x;
         __threadfence_system();                  /* halo puts of the preceding kernels first */
-        for (int p = 0; p < v.world; ++p) {
-            DistMail* m = &d->win[p]->mail[par][v.rank];
-            SYS_STORE(&m->v[0], vals[0]); SYS_STORE(&m->v[1], vals[1]); SYS_STORE(&m->v[2], vals[2]);
-        }
+        DistMail* m = &d->win[p]->mail[par][v.rank];
+        SYS_STORE(&m->v[0], vals[0]); SYS_STORE(&m->v[1], vals[1]); SYS_STORE(&m->v[2], vals[2]);
         __threadfence_system();
-        for (int p = 0; p < v.world; ++p)
-            __hip_atomic_store(&d->win[p]->mail[par][v.rank].seq, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        double acc[3] = {0., 0., 0.};
+        __hip_atomic_store(&m->seq, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        DistMail* in = &d->win[v.rank]->mail[par][p];
         bool ok = true;
         const long long t0 = wall_clock64();     /* 100 MHz */
-        for (int p = 0; p < v.world && ok; ++p) {
-            DistMail* m = &d->win[v.rank]->mail[par][p];
-            while (__hip_atomic_load(&m->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
-                __builtin_amdgcn_s_sleep(1);
-                if (wall_clock64() - t0 > 6000000000LL) { ok = false; break; }   /* 60 s at 100 MHz */
-            }
-            if (!ok) break;
-            for (int k = 0; k < 3; ++k) {
-                const double x = SYS_LOAD(&m->v[k]);
-                if (p == 0) acc[k] = x;
-                else acc[k] = op ? dmax(acc[k], x) : acc[k] + x;
-            }
+        while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 6000000000LL) { ok = false; break; }   /* 60 s at 100 MHz */
         }
+        if (ok) for (int k = 0; k < 3; ++k) shIn[p][k] = SYS_LOAD(&in->v[k]);
+        else shOk = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc[3] = {0., 0., 0.};
+        if (shOk)
+            for (int p = 0; p < v.world; ++p)    /* rank order: identical bits on every rank */
+                for (int k = 0; k < 3; ++k) {
+                    const double x = shIn[p][k];
+                    if (p == 0) acc[k] = x;
+                    else acc[k] = op ? dmax(acc[k], x) : acc[k] + x;
+                }
         sh[0] = acc[0]; sh[1] = acc[1]; sh[2] = acc[2];
-        shOk = ok ? 1 : 0;
         c->epoch = e + 1;
-        if (!ok) { c->distError = 1; c->stage = ST_FAIL; }
+        if (!shOk) { c->distError = 1; c->stage = ST_FAIL; }
     }
     __syncthreads();
     vals[0] = sh[0]; vals[1] = sh[1]; vals[2] = sh[2];
@@ -1511,6 +1515,15 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             v.nbSurf = blocks(v.nListSurf); if (v.nbSurf == 0) v.nbSurf = 1;
             v.nbSoil = blocks(v.nList - v.nListSurf);
             v.world = world_; v.rank = rank_;
+        }
+        if (world_ > 1) {
+            /* chunks that owe values to a neighbouring rank go first: their halo puts are on the wire while the interior
+             * is still being computed, instead of being the last thing every sweep waits for */
+            std::vector<uint8_t> owes(nChunks, 0);
+            for (int pr = 0; pr < world_; ++pr) for (uint32_t node : I.part.send[pr]) owes[node / SF3D_CHUNK] = 1;
+            auto first = [&](uint32_t q) { return owes[q] != 0; };
+            std::stable_partition(listSurf.begin(), listSurf.end(), first);
+            std::stable_partition(listSoil.begin(), listSoil.end(), first);
         }
         listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
         {   /* XCD banding.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and walks the list in groups of four
