@@ -635,3 +635,66 @@ def soil_only_column(n_nodes: int = 40, dz: float = 0.05) -> Model:
                  link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8), link_area=np.ones(len(ln)),
                  soil_index=np.zeros(n, np.uint16), soils=[LOAM], psi0_soil=-2.5, numerics=(1.0, 3600.0, 150, 10, 10, 3),
                  cell_area=1.0, shape=(1, 1, n), meta=dict(kind="soil_only", prescribed_node=0, prescribed_H=-0.2))
+
+
+def random_model(seed: int, nx: int = 9, ny: int = 8, nz: int = 5) -> Model:
+    """Randomised irregular graph for fuzz tests: random holes, random column depths, random layer thickness per
+    column, a random subset of the eight lateral neighbours linked (so chunks mix link kinds and index offsets),
+    random soils out of the 12 USDA classes, random boundary types on edge and bottom nodes, random relief."""
+    rng = np.random.RandomState(seed)
+    cell = float(rng.choice([2.0, 5.0, 10.0]))
+    area = cell * cell
+    valid = rng.rand(ny, nx) > 0.12
+    valid[ny // 2, nx // 2] = True
+    layers = rng.randint(1, nz, size=(ny, nx))                  # soil layers per column: 1 .. nz-1
+    thick = rng.choice([0.05, 0.1, 0.2], size=nz - 1)
+    relief = rng.rand(ny, nx) * 1.5 + 0.05 * np.arange(nx)[None, :] * cell + 0.03 * np.arange(ny)[:, None] * cell + 50.0
+    index = -np.ones((nz, ny, nx), np.int64)
+    n = 0
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                if valid[r, c] and (l == 0 or l <= layers[r, c]):
+                    index[l, r, c] = n; n += 1
+    ns = int((index[0] >= 0).sum())
+    x = np.zeros(n); y = np.zeros(n); z = np.zeros(n); size = np.zeros(n)
+    surf = np.zeros(n, np.uint8); btype = np.zeros(n, np.uint8); bslope = np.zeros(n); barea = np.zeros(n)
+    soil_index = np.zeros(n - ns, np.uint16)
+    ln, lt, ld, la = [], [], [], []
+    top = np.concatenate([[0.0], np.cumsum(thick)[:-1]])
+    for l in range(nz):
+        for r in range(ny):
+            for c in range(nx):
+                i = index[l, r, c]
+                if i < 0:
+                    continue
+                x[i], y[i] = c * cell, r * cell
+                edge = r in (0, ny - 1) or c in (0, nx - 1)
+                if l == 0:
+                    z[i] = relief[r, c]; size[i] = area; surf[i] = 1
+                    if edge and rng.rand() < 0.5:
+                        btype[i] = capi.BND_RUNOFF; bslope[i] = 0.02 + 0.05 * rng.rand(); barea[i] = cell
+                else:
+                    z[i] = relief[r, c] - (top[l - 1] + 0.5 * thick[l - 1]); size[i] = area * thick[l - 1]
+                    soil_index[i - ns] = rng.randint(0, 12)
+                    last = (l + 1 >= nz) or index[l + 1, r, c] < 0
+                    if last:
+                        btype[i] = rng.choice([capi.BND_FREE_DRAINAGE, capi.BND_NONE], p=[0.7, 0.3]); barea[i] = area
+                    elif edge and rng.rand() < 0.5:
+                        btype[i] = capi.BND_FREE_LATERAL_DRAINAGE; bslope[i] = 0.03; barea[i] = cell * thick[l - 1]
+                if l > 0:
+                    ln.append(i); lt.append(index[l - 1, r, c]); ld.append(capi.LINK_UP); la.append(area)
+                if l + 1 < nz and index[l + 1, r, c] >= 0:
+                    ln.append(i); lt.append(index[l + 1, r, c]); ld.append(capi.LINK_DOWN); la.append(area)
+                lat = cell if l == 0 else cell * thick[l - 1]
+                for dr, dc in LATERAL_OFFSETS:
+                    rr, cc = r + dr, c + dc
+                    # the same coin for both directions of a link: keyed on the unordered cell pair
+                    key = hash((seed, l, min((r, c), (rr, cc)), max((r, c), (rr, cc)))) % 100
+                    if 0 <= rr < ny and 0 <= cc < nx and index[l, rr, cc] >= 0 and key < 80:
+                        ln.append(i); lt.append(index[l, rr, cc]); ld.append(capi.LINK_LATERAL); la.append(lat * 0.5)
+    return Model(n=n, ns=ns, x=x, y=y, z=z, size=size, is_surface=surf, btype=btype, bslope=bslope, barea=barea,
+                 link_node=np.array(ln, np.uint32), link_to=np.array(lt, np.uint32), link_dir=np.array(ld, np.uint8),
+                 link_area=np.array(la), soil_index=soil_index, soils=usda_soils(), psi0_soil=float(-0.5 - 3.0 * rng.rand()),
+                 lv_ratio=float(rng.choice([1.0, 4.0, 10.0])), numerics=(0.5, 3600.0, 150, 10, 10, 3), cell_area=area,
+                 shape=(nx, ny, nz), meta=dict(kind="random", seed=seed))
