@@ -27,6 +27,8 @@ elif case == "het":
     m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
 elif case == "ragged":
     m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
+elif case == "random":
+    m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
 elif case == "heat":
     m, plan = cm.with_heat_surface(cm.catchment_model(40, 48, 6, heterogeneous=True)), [4.0, 0.0]
 else:

@@ -43,6 +43,8 @@ def oracle_reference(oracle, case):
         m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
     elif case == "het":
         m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
+    elif case == "random":
+        m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
     else:
         m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
     oracle.lib.sf3d_reset_solver_state()
@@ -55,7 +57,7 @@ def oracle_reference(oracle, case):
     return m, out
 
 
-@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614)])
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614), (3, "random", 29615)])
 def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
     ranks = run_ranks(world, case, tmp_path, port)
     m, ref = oracle_reference(oracle, case)
