@@ -482,6 +482,7 @@ __device__ __forceinline__ void accept_bookkeeping(Ctrl* c)
     c->prevStep.sinkSource = c->curStep.sinkSource;
     c->curPeriod.sinkSource += c->curStep.sinkSource;
     c->counters[1]++;
+    c->acceptDt = c->dt; c->acceptBuf = c->cur;
     c->stage = ST_ACCEPT;              /* k_accept (flow sums) is the last kernel of the step */
 }
 __device__ __forceinline__ void halve_and_reject(Ctrl* c)
@@ -1178,6 +1179,49 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     }
 }
 
+/* The two halves of k_accept for the overlapped mode: the boundary sums stay in the step (the next step's k_props
+ * overwrites bflowRate); the link sums - 1.5 GB of traffic at C4, 6 % VALU - run on a second stream next to the next
+ * step's k_props (68 % VALU, little traffic), which must only finish before that step's first k_assemble rewrites A2. */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_accept_boundary(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_ACCEPT) return;
+    const double dt = c->dt;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (NOT_MINE(v, i)) continue;
+        if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
+    }
+}
+template <bool NT>
+__global__ void __launch_bounds__(SF3D_BLOCK) k_accept_links(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    const double* __restrict__ X = v.X[c->acceptBuf];
+    const sf3d_d2* __restrict__ A2 = v.A2;
+    const double dt = c->acceptDt;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (NOT_MINE(v, i)) continue;
+        double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
+        uint32_t j[SF3D_SLOTS];
+        #pragma unroll
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+        const ChunkDesc cd = v.cdesc[q];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
+            else j[s] = i + cd.delta[s];
+        }
+        const double Hi = X[i];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? load_stream<NT>(&v.lflowSum[(size_t)s * v.N + i]) : 0.; }
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s)
+            if (a[s] != 0.) store_stream<NT>(&v.lflowSum[(size_t)s * v.N + i], f[s] + a[s] * (Hi - xj[s]) * dt);
+    }
+}
+
 /* computeTotalWaterContent on the stored state (getTotalWaterContent / initializeBalance) */
 __global__ void __launch_bounds__(SF3D_BLOCK) k_storage(DevView v)
 {
@@ -1281,6 +1325,10 @@ sf3d_error_t sf3d_compute_partition(const HostModel& m, int rank, int world, Par
 struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;         /* link flow sums of the accepted step, next to the next step's k_props */
+    hipEvent_t evLinks = nullptr;
+    bool linksPending = false;
+    int overlapAccept = -1;                /* SF3D_OVERLAP_ACCEPT=0 keeps k_accept inside the step */
     DevView v{};
     Ctrl* hostCtrl = nullptr;              /* pinned */
     std::vector<void*> allocs;
@@ -1338,6 +1386,8 @@ sf3d_error_t DeviceSolver::release()
     if (!impl_) return SF3D_OK;
     Impl& I = *impl_;
     if (I.stream) hipStreamSynchronize(I.stream);
+    if (I.stream2) hipStreamSynchronize(I.stream2);
+    I.linksPending = false;
     for (auto& p : I.pending) { I.freeEvents.push_back(p.a); I.freeEvents.push_back(p.b); }
     I.pending.clear();
     for (auto& g : I.graphs) hipGraphExecDestroy(g.second);
@@ -1357,6 +1407,7 @@ sf3d_error_t DeviceSolver::synchronize()
 {
     if (!impl_ || !impl_->stream) return SF3D_OK;
     HIP_TRY(hipStreamSynchronize(impl_->stream));
+    if (impl_->stream2) { HIP_TRY(hipStreamSynchronize(impl_->stream2)); impl_->linksPending = false; }
     return SF3D_OK;
 }
 
@@ -1391,6 +1442,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
     }
     HIP_TRY(hipSetDevice(I.device));
     if (!I.stream) HIP_TRY(hipStreamCreateWithFlags(&I.stream, hipStreamNonBlocking));
+    if (!I.stream2) { HIP_TRY(hipStreamCreateWithFlags(&I.stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks, hipEventDisableTiming)); }
+    if (I.linksPending && (m.graphDirty || m.stateDirty || m.flowSumsDirty || !built_)) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending = false; }
     if (!I.hostCtrl) HIP_TRY(hipHostMalloc((void**)&I.hostCtrl, sizeof(Ctrl), hipHostMallocDefault));
 
     const uint32_t N = m.N, ns = m.ns;
@@ -1820,6 +1873,7 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
 {
     Impl& I = *impl_;
     const size_t N = m.N;
+    if (I.stream2) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending = false; }     /* link flow sums of the last step */
     HIP_TRY(hipMemcpyAsync(m.bflowSum.data(), I.v.bflowSum, N * 8, hipMemcpyDeviceToHost, I.stream));
     HIP_TRY(hipMemcpyAsync(m.bflowRate.data(), I.v.bflowRate, N * 8, hipMemcpyDeviceToHost, I.stream));
     for (int s = 0; s < SF3D_SLOTS; ++s)
@@ -1991,6 +2045,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* mode 2 samples: the sweeps of every 4th computeStep carry HIP events (eager launches); the other
      * steps replay hipGraphs, so the measurement costs ~1.5 % instead of ~6 % */
     const bool timedStep = I.timing == 1 || (I.timing == 2 && (I.stepSeq++ % 4 == 0));
+    if (I.overlapAccept < 0) { const char* oe = getenv("SF3D_OVERLAP_ACCEPT"); I.overlapAccept = (oe && oe[0] == '0') ? 0 : 1; }
+    /* accepted step: link flow sums on a second stream next to the next step's k_props (untimed steps only, so that the
+     * per-kernel event timing of --time-all-kernels stays a sequence of exclusive launches) */
+    const bool overlap = I.overlapAccept && !timedStep && I.timing != 1;
     auto timed = [&](int kid, auto launch) {
         if (!timedStep || (I.timing == 2 && kid != KID_SWEEP)) { launch(); return; }
         hipEvent_t a, b;
@@ -2015,8 +2073,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     int guard = 0;
 
     /* one approximation's worth of guarded kernels */
-    auto enqueue_batch = [&](bool withHead, bool withTail) {
-        if (withHead) {
+    auto enqueue_props = [&] {
             if (heatOn && multi) {      /* sharded heat always uses the fused exchange; halo conductivities are recomputed locally */
                 timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, true>), grid, block, 0, st, v); });
                 hipLaunchKernelGGL(k_heat_halo_water, pgrid, block, 0, st, v);
@@ -2028,6 +2085,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
+    };
+    auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps) {
+        if (withHead) {
+            if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
             else if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
@@ -2058,7 +2119,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 timed(KID_RESTORE, [&] { if (heatOn) hipLaunchKernelGGL((k_restore<false, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_restore<false, false>), grid, block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
             }
-            timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, grid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, grid, block, 0, st, v); });
+            if (overlap) hipLaunchKernelGGL(k_accept_boundary, grid, block, 0, st, v);
+            else timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, grid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, grid, block, 0, st, v); });
         }
     };
 
@@ -2068,17 +2130,17 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* The ~25 launches of a batch are replayed from an instantiated hipGraph (one per shape): small
      * grids are bound by the host's launch rate otherwise.  Event timing needs eager launches. */
     if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
-    auto launch_batch = [&](bool withHead, bool withTail) -> hipError_t {
-        if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail); return hipSuccess; }
+    auto launch_batch = [&](bool withHead, bool withTail, bool skipProps) -> hipError_t {
+        if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps); return hipSuccess; }
         uint32_t chunk = I.lastSweeps + 2;
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return e;
-        enqueue_batch(withHead, withTail);
+        enqueue_batch(withHead, withTail, skipProps);
         e = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess) return e;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -2090,8 +2152,19 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
 
     uint32_t look = I.lastBatches < 1 ? 1 : (I.lastBatches > 6 ? 6 : I.lastBatches);
     while (true) {
-        for (uint32_t bq = 0; bq < look; ++bq)
-            HIP_TRY(launch_batch(bq > 0 || stage == ST_APPROX, bq + 1 == look));
+        for (uint32_t bq = 0; bq < look; ++bq) {
+            const bool head = bq > 0 || stage == ST_APPROX;
+            bool skipProps = false;
+            if (head && I.linksPending) {
+                /* the previous step's link flow sums may still be reading A2 on the second stream: this step's k_props
+                 * runs next to them, the first k_assemble (which rewrites A2) waits for them */
+                enqueue_props();
+                HIP_TRY(hipStreamWaitEvent(st, I.evLinks, 0));
+                I.linksPending = false;
+                skipProps = true;
+            }
+            HIP_TRY(launch_batch(head, bq + 1 == look, skipProps));
+        }
         look = 1;
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
@@ -2129,6 +2202,15 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     {   /* approximations this step took (rejected attempts included) = batches the next one will queue up front */
         const uint64_t used = I.hostCtrl->counters[2] - atStart[2];
         I.lastBatches = used < 1 ? 1u : (uint32_t)used;
+    }
+    if (overlap && stage == ST_ACCEPT) {
+        /* the main stream is drained (the poll just read the control block): no dependency to express for the launch */
+        uint32_t lcap = 384u; if (const char* le = getenv("SF3D_LINKS_BLOCKS")) lcap = (uint32_t)atoi(le);      /* measured at C4: 2048 -1 %, 512 / 256 +1 %, 128 -4 % */
+        const dim3 lgrid(v.nb > lcap ? lcap : v.nb);        /* a streaming kernel: few enough waves that k_props fits next to it */
+        if (v.ntStream) hipLaunchKernelGGL(k_accept_links<true>, lgrid, block, 0, I.stream2, v);
+        else hipLaunchKernelGGL(k_accept_links<false>, lgrid, block, 0, I.stream2, v);
+        HIP_TRY(hipEventRecord(I.evLinks, I.stream2));
+        I.linksPending = true;
     }
     }   /* if (m.water) */
 

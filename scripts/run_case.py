@@ -24,6 +24,11 @@ for h, (mm, mx) in enumerate(plan):
     _, dts = cm.run_hour(sf, m, mm, max_steps=mx)
     s = cm.snapshot(sf, m)
     res[f"H{h}"] = s["H"]; res[f"Se{h}"] = s["Se"]; res[f"dts{h}"] = np.array(dts); res[f"storage{h}"] = np.array(s["storage"])
+# per-node lateral flow sums and boundary sums of the last hour: the link flow sums are added by their own kernel
+res["lateral_in"] = np.array([sf.lib.sf3d_get_node_sum_lateral_water_flow_in(int(i)) for i in range(0, m.n, max(1, m.n // 4096))])
+res["lateral_out"] = np.array([sf.lib.sf3d_get_node_sum_lateral_water_flow_out(int(i)) for i in range(0, m.n, max(1, m.n // 4096))])
+res["down"] = np.array([sf.lib.sf3d_get_node_max_water_flow(int(i), capi.LINK_DOWN) for i in range(0, m.n, max(1, m.n // 4096))])
+res["boundary"] = sf.boundary_water_flow(0, m.n)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
 np.savez(out, **res)

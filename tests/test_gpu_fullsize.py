@@ -75,21 +75,23 @@ def test_c4_state_round_trip_is_idempotent(product, c4):
 def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
     """The single-GPU fast path (sweep + convergence decision fused through a last-block hand-off,
     batches replayed from hipGraphs) must give exactly the bits of the plain path (separate
-    decision kernel, eager launches): same partial-sum order, same decisions."""
+    decision kernel, eager launches), and so must the link flow sums added on a second stream next to the
+    next step (default) versus inside the step (SF3D_OVERLAP_ACCEPT=0): same partial-sum order, same decisions, same sums."""
     import os
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     outs = []
-    for fused, graphs in (("1", "1"), ("0", "0")):
-        out = tmp_path / f"{case}_{fused}{graphs}.npz"
-        env = dict(os.environ, SF3D_FUSED_DECIDE=fused, SF3D_GRAPHS=graphs)
+    for fused, graphs, overlap in (("1", "1", "1"), ("0", "0", "1"), ("1", "1", "0")):
+        out = tmp_path / f"{case}_{fused}{graphs}{overlap}.npz"
+        env = dict(os.environ, SF3D_FUSED_DECIDE=fused, SF3D_GRAPHS=graphs, SF3D_OVERLAP_ACCEPT=overlap)
         p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stdout + p.stderr
         outs.append(np.load(out))
-    a, b = outs
-    assert set(a.files) == set(b.files)
-    for k in a.files:
-        assert np.array_equal(a[k], b[k]), k
+    a = outs[0]
+    for b in outs[1:]:
+        assert set(a.files) == set(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), k
