@@ -200,7 +200,7 @@ def main():
         run_hours(sf, cm, model, args.forcing, args.warmup, heat=heat)
         fresh()
 
-    # HIP events around the dominant kernel only, on every 4th computeStep (mode 2); --time-all-kernels
+    # HIP events around the dominant kernel only, on every 8th computeStep (mode 2); --time-all-kernels
     # instruments every node kernel of every step (eager launches, ~6 % slower)
     sf.check(sf.lib.sf3d_kernel_timing(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2)), "kernel_timing")
     per_step, hour_starts = [], []

@@ -1352,7 +1352,7 @@ struct DeviceSolver::Impl {
     DistView* devDist = nullptr;
     uint32_t pushBlocks = 0;
     /* timing */
-    int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 4th step */
+    int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -2042,9 +2042,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
-    /* mode 2 samples: the sweeps of every 4th computeStep carry HIP events (eager launches); the other
-     * steps replay hipGraphs, so the measurement costs ~1.5 % instead of ~6 % */
-    const bool timedStep = I.timing == 1 || (I.timing == 2 && (I.stepSeq++ % 4 == 0));
+    /* mode 2 samples: the sweeps of every 8th computeStep carry HIP events (eager launches); the other
+     * steps replay hipGraphs, so the measurement costs ~1 % instead of ~6 % */
+    const bool timedStep = I.timing == 1 || (I.timing == 2 && (I.stepSeq++ % 8 == 0));
     if (I.overlapAccept < 0) { const char* oe = getenv("SF3D_OVERLAP_ACCEPT"); I.overlapAccept = (oe && oe[0] == '0') ? 0 : 1; }
     /* accepted step: link flow sums on a second stream next to the next step's k_props (untimed steps only, so that the
      * per-kernel event timing of --time-all-kernels stays a sequence of exclusive launches) */

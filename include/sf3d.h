@@ -341,7 +341,7 @@ sf3d_error_t sf3d_set_device(int device);
 sf3d_error_t sf3d_synchronize(void);
 /* Per-kernel HIP-event timing on the solver's own stream.  mode 1 records an event pair around
  * every launch of the kernels listed by sf3d_kernel_name(), mode 2 only around the Jacobi sweeps of
- * every 4th computeStep (the dominant kernel, sampled: ~1.5 % overhead), mode 0 stops.  Guarded launches that did no work are not counted. */
+ * every 8th computeStep (the dominant kernel, sampled: ~1 % overhead), mode 0 stops.  Guarded launches that did no work are not counted. */
 sf3d_error_t sf3d_kernel_timing(int mode);
 /* number of instrumented kernels; name of kernel k (NULL if out of range) */
 int          sf3d_kernel_count(void);
