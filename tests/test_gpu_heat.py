@@ -170,3 +170,13 @@ def test_reference_order_gauss_seidel_equals_jacobi(product, oracle, monkeypatch
         assert rel(gT, oT) < 1e-7, rel(gT, oT)           # same sweep order as the reference: libm last-ulp differences, amplified by the scheme
         assert rel(jT, gT) < 1e-7, rel(jT, gT)           # Jacobi vs Gauss-Seidel: both within the stopping tolerance of the solution
         assert rel(gH, oH) < 1e-7 and rel(jH, oH) < RTOL
+
+
+def test_heat_half_day(product, oracle):
+    """twelve hours of the synthetic diurnal atmosphere (cm.heat_forcing: night into afternoon), two rain hours, on a
+    32x32x6 12-soil catchment: the difference to the oracle stays inside 1e-6 over the whole run of coupled water + heat
+    with evaporation (24 h were run once: passed, 150 s of oracle time)"""
+    m = cm.with_heat_surface(cm.catchment_model(32, 32, 6, heterogeneous=True))
+    rains = [0.0] * 12
+    rains[2] = 3.0; rains[8] = 1.5
+    run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), rains)
