@@ -63,7 +63,7 @@ struct ChunkDesc {
     int32_t delta[SF3D_SLOTS];          /* j - i when kind[s] is a uniform link kind, else 0 */
     uint8_t kind[SF3D_SLOTS];           /* CK_NONE | LK_* (uniform) | CK_MIXED */
     uint8_t rowType;                    /* 0 all surface nodes, 1 all soil nodes, 2 straddles nrSurfaceNodes */
-    uint8_t pad0;
+    uint8_t pad0;                       /* multi GPU: 1 = some node of the chunk has a neighbour owned by another rank */
     uint16_t areaUniform;               /* bit s: every link of slot s in the chunk has interface area area[s] */
     uint8_t pad1[10];
     double area[SF3D_SLOTS];            /* (cell size and layer thickness make it constant over regular grids) */
@@ -150,8 +150,17 @@ struct DistView {
      * destination rank and the position in that rank's send list */
     const uint32_t* bndStart;           /* [nChunks + 1] */
     const uint8_t* bndLane; const uint8_t* bndPeer; const uint32_t* bndSlot;
+    /* [10][N]: where the value of a FOREIGN neighbour arrives in my window (SF3D_FSRC_NONE for local neighbours); read only
+     * in chunks whose descriptor is flagged (ChunkDesc::pad0): the sweeps take foreign neighbours straight from the payload */
+    const uint32_t* fsrc;
 };
-/* payload layout per (receiver, source p): [parity 0/1][field 0/1][count] doubles at offset off[p] */
+/* payload layout per (receiver, source p): [parity 0/1][field][count] doubles at offset off[p];
+ * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate
+ * fields because the x of the LAST sweep of an approximation is consumed late (by the readers' k_post), after a fast
+ * neighbour may already have put the K of the next approximation into the same parity. */
+#define SF3D_DIST_FIELDS 3
+enum { DF_X = 0, DF_K = 1, DF_FLOW = 2 };
+#define SF3D_FSRC_NONE 0xFFFFFFFFu      /* fsrc: (source rank << 27) | position in that rank's send list */
 
 /* coupled heat transport (heat.cpp): everything the heat kernels and the heat terms of the water kernels
  * need; `on` = 0 leaves every pointer null */
@@ -185,6 +194,8 @@ struct DevView {
     /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
+    uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once
+                                           per approximation (k_post) instead of once per sweep, off the critical path (SF3D_HALO_DIRECT=0: old way) */
     uint32_t ntStream;                  /* 1: streamed-once arrays (coefficients, link geometry, flow sums) bypass the caches
                                            (they would evict x, b, z from the 256 MiB Infinity Cache); 0 when the whole
                                            working set of a rank fits the cache (small grids, 8-way sharding) */

@@ -246,7 +246,7 @@ __device__ __forceinline__ void dist_unpack(const DevView& v, uint32_t par, int 
     for (int p = 0; p < v.world; ++p) {
         const uint32_t cnt = d->recvCount[p];
         if (cnt == 0) continue;
-        const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * 2 + field) * cnt;
+        const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         const uint32_t* idx = d->recvIdx[p];
         for (uint32_t k0 = threadIdx.x; k0 < cnt; k0 += SF3D_BLOCK * U) {
             double val[U]; uint32_t id[U];
@@ -272,7 +272,7 @@ __device__ __forceinline__ void dist_push(const DevView& v, uint32_t par, int fi
     for (int p = 0; p < v.world; ++p) {
         const uint32_t cnt = d->sendCount[p];
         if (cnt == 0) continue;
-        double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * 2 + field) * cnt;
+        double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         const uint32_t* idx = d->sendIdx[p];
         for (uint32_t k = tid; k < cnt; k += nth) SYS_STORE(&dst[k], src[idx[k]]);
     }
@@ -291,8 +291,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_push_kf(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
-    dist_push(v, c->epoch & 1u, 0, v.K);
-    dist_push(v, c->epoch & 1u, 1, v.flow);
+    dist_push(v, c->epoch & 1u, DF_K, v.K);
+    dist_push(v, c->epoch & 1u, DF_FLOW, v.flow);
     __threadfence_system();
 }
 /* barrier + halo of K / waterFlow before the assembly reads neighbours */
@@ -304,8 +304,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sync_kf(DevView v)
     __syncthreads();
     double vals[3] = {0., 0., 0.};
     if (!dist_allgather(v, c, vals, 0)) return;
-    dist_unpack(v, par, 0, v.K);
-    dist_unpack(v, par, 1, v.flow);
+    dist_unpack(v, par, DF_K, v.K);
+    dist_unpack(v, par, DF_FLOW, v.flow);
 }
 
 /* ---- last-block hand-off inside a launch ---------------------------------------------------
@@ -356,7 +356,7 @@ __device__ __forceinline__ void dist_put_chunk(const DevView& v, uint32_t q, uin
         const double x = __shfl(val, on ? (int)d->bndLane[t] : 0, 64);
         if (on) {
             const uint32_t p = d->bndPeer[t];
-            double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * 2 + field) * d->sendCount[p] + d->bndSlot[t];
+            double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * d->sendCount[p] + d->bndSlot[t];
             SYS_STORE(dst, x);
         }
     }
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
             boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
             if (MODE == 2) fl = v.flow[i];
         }
-        if (MODE == 2) { dist_put_chunk(v, q, lane_, par, 0, K); dist_put_chunk(v, q, lane_, par, 1, fl); }
+        if (MODE == 2) { dist_put_chunk(v, q, lane_, par, DF_K, K); dist_put_chunk(v, q, lane_, par, DF_FLOW, fl); }
     }
     if (MODE != 2) return;
     /* multi GPU: barrier across ranks + halo of K / waterFlow before the assembly reads neighbours */
@@ -753,8 +753,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
     if (!arrive_last(v, 0., 0., false)) return;
     double vals[3] = {0., 0., 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;
-    dist_unpack(v, par, 0, v.K);
-    dist_unpack(v, par, 1, v.flow);
+    dist_unpack(v, par, DF_K, v.K);
+    dist_unpack(v, par, DF_FLOW, v.flow);
 }
 
 /* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
@@ -1028,6 +1028,21 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
             const double bi = v.b[i], zi = v.z[i], xi = xin[i];
             #pragma unroll
             for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
+            if (MODE == 2 && v.haloDirect && cd.pad0 && c->iter > 0) {
+                /* multi GPU, second and later sweeps of an approximation: the neighbours' previous iterate sits in my window
+                 * (they put it during their previous sweep, parity of the previous epoch) and has not been copied into xin -
+                 * the halo copy is done once per approximation by k_post, not once per sweep on the critical path */
+                const DistView* d = v.dist;
+                const uint32_t parPrev = par ^ 1u;
+                #pragma unroll
+                for (int s = 0; s < SF3D_SLOTS; ++s) {
+                    const uint32_t f = d->fsrc[(size_t)s * v.N + i];
+                    if (f != SF3D_FSRC_NONE) {
+                        const uint32_t p = f >> 27, k = f & 0x07FFFFFFu;
+                        xj[s] = SYS_LOAD(d->payload[v.rank] + d->recvOff[p] + (size_t)(parPrev * SF3D_DIST_FIELDS + DF_X) * d->recvCount[p] + k);
+                    }
+                }
+            }
             xn = bi;
             constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
             #pragma unroll
@@ -1053,8 +1068,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     if (!arrive_last(v, bs, 0., false)) return;
     double vals[3] = {sum_published(v.part0, gridDim.x), 0., 0.};
     if (MODE == 2) {
-        if (!dist_allgather(v, v.ctrl, vals, 0)) return;
-        dist_unpack(v, par, 0, v.X[nxt]);                                 /* neighbours' new iterate on my halo */
+        if (!dist_allgather(v, v.ctrl, vals, 0)) return;                  /* also the barrier that makes the neighbours' puts visible */
+        if (!v.haloDirect) dist_unpack(v, par, DF_X, v.X[nxt]);           /* neighbours' new iterate on my halo */
     }
     if (threadIdx.x == 0) sweep_decision(v.ctrl, nxt, vals[0] / v.N);
 }
@@ -1079,7 +1094,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_POST) return;
-    const double* __restrict__ Xc = v.X[c->cur];
+    const int cur = c->cur;
+    const uint32_t parLastSweep = (c->epoch - 1u) & 1u;       /* the last sweep put its iterate one epoch ago */
+    const double* __restrict__ Xc = v.X[cur];
     double st = 0., sk = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
@@ -1097,6 +1114,10 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
     if (!arrive_last(v, a, b, true)) return;              /* last block: evaluateWaterBalance */
     double vals[3] = {sum_published(v.part0, gridDim.x), sum_published(v.part1, gridDim.x), 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;
+    if (v.world > 1 && v.haloDirect) {                    /* the halo of the final iterate, once per approximation: the sweeps read */
+        dist_unpack(v, parLastSweep, DF_X, v.X[cur]);     /* foreign neighbours straight from the window                            */
+        __syncthreads();
+    }
     if (threadIdx.x == 0) balance_decision(v.ctrl, vals[0], vals[1]);
 }
 
@@ -1131,7 +1152,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
             boundary_update<HEAT>(v, c, i, H, Ho, z, K, Se);
             balance_terms(v, c, i, H, z, Se, st, sk);
         }
-        if (haloK) dist_put_chunk(v, q, lane_, par, 0, K);
+        if (haloK) dist_put_chunk(v, q, lane_, par, DF_K, K);
     }
     if (haloK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const double a = block_sum(st), b = block_sum(sk);
@@ -1142,7 +1163,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     if (!arrive_last(v, a, b, true)) return;
     double vals[3] = {sum_published(v.part0, gridDim.x), sum_published(v.part1, gridDim.x), 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;
-    if (haloK) dist_unpack(v, par, 0, v.K);
+    if (haloK) dist_unpack(v, par, DF_K, v.K);
     if (threadIdx.x == 0) restore_decision(v.ctrl, vals[0], vals[1]);
 }
 
@@ -1442,7 +1463,6 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
     }
     HIP_TRY(hipSetDevice(I.device));
     if (!I.stream) HIP_TRY(hipStreamCreateWithFlags(&I.stream, hipStreamNonBlocking));
-    if (!I.stream2) { HIP_TRY(hipStreamCreateWithFlags(&I.stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks, hipEventDisableTiming)); }
     if (I.linksPending && (m.graphDirty || m.stateDirty || m.flowSumsDirty || !built_)) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending = false; }
     if (!I.hostCtrl) HIP_TRY(hipHostMalloc((void**)&I.hostCtrl, sizeof(Ctrl), hipHostMallocDefault));
 
@@ -1646,7 +1666,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             for (int pr = 0; pr < world_; ++pr) {
                 d.recvCount[pr] = (uint32_t)I.part.recv[pr].size();
                 d.recvOff[pr] = off;
-                off += (uint64_t)d.recvCount[pr] * 4;
+                off += (uint64_t)d.recvCount[pr] * 2 * SF3D_DIST_FIELDS;
                 d.sendCount[pr] = (uint32_t)I.part.send[pr].size();
                 if (d.sendCount[pr] > maxSend) maxSend = d.sendCount[pr];
                 uint32_t *si, *ri;
@@ -1678,6 +1698,30 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     HIP_TRY(hipMemcpy(dpe, bpeer.data(), bpeer.size(), hipMemcpyHostToDevice));
                 }
                 d.bndStart = dbs; d.bndSlot = dsl; d.bndLane = dla; d.bndPeer = dpe;
+            }
+            if (I.useFused < 0) { const char* fe = getenv("SF3D_FUSED_DECIDE"); I.useFused = (fe && fe[0] == '0') ? 0 : 1; }
+            v.haloDirect = I.useFused != 0 ? 1u : 0u;      /* the fused exchange only; SF3D_HALO_DIRECT=0 copies the halo after every sweep */
+            if (const char* hd = getenv("SF3D_HALO_DIRECT")) v.haloDirect = (hd[0] == '1' && I.useFused != 0) ? 1u : 0u;
+            if (v.haloDirect) {   /* where each foreign neighbour's value arrives in my window; chunks that have any are flagged */
+                std::vector<uint32_t> fsrc(NS, SF3D_FSRC_NONE);
+                for (uint32_t i = 0; i < N; ++i) {
+                    if (I.part.owner[i] != rank_) continue;
+                    for (int sl = 0; sl < SF3D_SLOTS; ++sl) {
+                        const size_t e = (size_t)sl * N + i;
+                        if (kind[e] == LK_NONE) continue;
+                        const uint32_t j = to[e];
+                        const int pr = I.part.owner[j];
+                        if (pr == rank_) continue;
+                        const auto& lst = I.part.recv[pr];
+                        const auto it = std::lower_bound(lst.begin(), lst.end(), j);
+                        if (it == lst.end() || *it != j) { snprintf(err_, sizeof(err_), "partition: node %u read by %u is missing from the halo list of rank %d", j, i, pr); return SF3D_TOPOGRAPHY_ERROR; }
+                        fsrc[e] = ((uint32_t)pr << 27) | (uint32_t)(it - lst.begin());
+                        cdesc[i / SF3D_CHUNK].pad0 = 1;
+                    }
+                }
+                uint32_t* dfs; HIP_TRY(dev_alloc(I.allocs, dfs, NS));
+                HIP_TRY(hipMemcpy(dfs, fsrc.data(), NS * 4, hipMemcpyHostToDevice));
+                d.fsrc = dfs;
             }
             I.windowBytes = sizeof(DistWindow) + off * sizeof(double);
             void* w = nullptr;
@@ -2046,9 +2090,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
      * steps replay hipGraphs, so the measurement costs ~1 % instead of ~6 % */
     const bool timedStep = I.timing == 1 || (I.timing == 2 && (I.stepSeq++ % 8 == 0));
     if (I.overlapAccept < 0) { const char* oe = getenv("SF3D_OVERLAP_ACCEPT"); I.overlapAccept = (oe && oe[0] == '0') ? 0 : 1; }
+    /* single GPU only: a second stream per process is a second hardware queue, and ranks that share a GPU (functional
+     * multi-rank tests) oversubscribe the queues - their spinning exchange kernels then wait for time slices (measured: 45x slower) */
+    if (I.overlapAccept && !multi && !I.stream2) { HIP_TRY(hipStreamCreateWithFlags(&I.stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks, hipEventDisableTiming)); }
     /* accepted step: link flow sums on a second stream next to the next step's k_props (untimed steps only, so that the
      * per-kernel event timing of --time-all-kernels stays a sequence of exclusive launches) */
-    const bool overlap = I.overlapAccept && !timedStep && I.timing != 1;
+    const bool overlap = I.overlapAccept && !multi && I.stream2 && !timedStep && I.timing != 1;
     auto timed = [&](int kid, auto launch) {
         if (!timedStep || (I.timing == 2 && kid != KID_SWEEP)) { launch(); return; }
         hipEvent_t a, b;
