@@ -104,6 +104,7 @@ struct Ctrl {
     uint32_t linearValid;
     uint32_t epoch;         /* exchange counter, identical on every rank (multi-GPU) */
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
+    uint32_t kfEpoch, haloEpoch, haloPar; int32_t haloBuf;   /* multi GPU: which exchange the many-block halo copies (k_halo_copy) belong to */
     int32_t acceptBuf;      /* pool index of the accepted H: the link flow sums of the step are added from it ... */
     double acceptDt;        /* ... with this dt, possibly while the next step's first kernels already run */
     /* ---- balances (balanceData_t x4, soilFluxes3D.cpp:37) ---- */

@@ -752,9 +752,45 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
     __syncthreads();
     if (!arrive_last(v, 0., 0., false)) return;
     double vals[3] = {0., 0., 0.};
-    if (!dist_allgather(v, v.ctrl, vals, 0)) return;
-    dist_unpack(v, par, DF_K, v.K);
-    dist_unpack(v, par, DF_FLOW, v.flow);
+    if (!dist_allgather(v, v.ctrl, vals, 0)) return;          /* the barrier: every neighbour's K and waterFlow have landed */
+    if (threadIdx.x == 0) v.ctrl->kfEpoch = v.ctrl->epoch;     /* k_halo_copy<0> (next launch, many blocks) copies them in */
+}
+
+/* The halo copies that used to run in the ONE block that closes an exchange (20 000 system-scope loads at 8-way C4,
+ * tens of microseconds on the critical path of every approximation) as a launch of their own with many blocks.
+ * WHAT 0: K and waterFlow after k_props; WHAT 1: the final iterate of the sweeps after k_post.  Each copy is tied to the
+ * epoch its exchange closed, so a launch queued in vain (guarded no-op batches) copies nothing stale. */
+template <int WHAT>
+__global__ void __launch_bounds__(SF3D_BLOCK) k_halo_copy(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (v.world <= 1) return;
+    const DistView* d = v.dist;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (WHAT == 0) {
+        if (c->stage != ST_APPROX || c->kfEpoch != c->epoch) return;
+        const uint32_t par = (c->epoch - 1u) & 1u;
+        for (int p = 0; p < v.world; ++p) {
+            const uint32_t cnt = d->recvCount[p];
+            const uint32_t* idx = d->recvIdx[p];
+            const double* base = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * SF3D_DIST_FIELDS) * cnt;
+            for (uint32_t k = tid; k < cnt; k += nth) {
+                const uint32_t i = idx[k];
+                v.K[i] = SYS_LOAD(&base[(size_t)DF_K * cnt + k]);
+                v.flow[i] = SYS_LOAD(&base[(size_t)DF_FLOW * cnt + k]);
+            }
+        }
+    } else {
+        if (c->haloEpoch != c->epoch) return;
+        double* __restrict__ dst = v.X[c->haloBuf];
+        const uint32_t par = c->haloPar;
+        for (int p = 0; p < v.world; ++p) {
+            const uint32_t cnt = d->recvCount[p];
+            const uint32_t* idx = d->recvIdx[p];
+            const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * SF3D_DIST_FIELDS + DF_X) * cnt;
+            for (uint32_t k = tid; k < cnt; k += nth) dst[idx[k]] = SYS_LOAD(&src[k]);
+        }
+    }
 }
 
 /* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
@@ -1114,11 +1150,13 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
     if (!arrive_last(v, a, b, true)) return;              /* last block: evaluateWaterBalance */
     double vals[3] = {sum_published(v.part0, gridDim.x), sum_published(v.part1, gridDim.x), 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;
-    if (v.world > 1 && v.haloDirect) {                    /* the halo of the final iterate, once per approximation: the sweeps read */
-        dist_unpack(v, parLastSweep, DF_X, v.X[cur]);     /* foreign neighbours straight from the window                            */
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        if (v.world > 1 && v.haloDirect) {                /* the halo of the final iterate, once per approximation (k_halo_copy<1>, */
+            Ctrl* w = v.ctrl;                             /* next launch): the sweeps read foreign neighbours from the window       */
+            w->haloBuf = cur; w->haloPar = parLastSweep; w->haloEpoch = w->epoch;
+        }
+        balance_decision(v.ctrl, vals[0], vals[1]);
     }
-    if (threadIdx.x == 0) balance_decision(v.ctrl, vals[0], vals[1]);
 }
 
 /* restoreBestStep, water.cpp:253-267 */
@@ -2123,10 +2161,11 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     auto enqueue_props = [&] {
             if (heatOn && multi) {      /* sharded heat always uses the fused exchange; halo conductivities are recomputed locally */
                 timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, true>), grid, block, 0, st, v); });
+                hipLaunchKernelGGL(k_halo_copy<0>, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_heat_halo_water, pgrid, block, 0, st, v);
             }
             else if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
-            else if (multi && fusedMulti) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); });
+            else if (multi && fusedMulti) { timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); }); hipLaunchKernelGGL(k_halo_copy<0>, pgrid, block, 0, st, v); }
             else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), grid, block, 0, st, v); });
             if (multi && !fusedMulti) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
@@ -2154,7 +2193,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }
-        if (I.useFused) timed(KID_POST, [&] { hipLaunchKernelGGL(k_post<true>, grid, block, 0, st, v); });
+        if (I.useFused) { timed(KID_POST, [&] { hipLaunchKernelGGL(k_post<true>, grid, block, 0, st, v); }); if (multi && v.haloDirect) hipLaunchKernelGGL(k_halo_copy<1>, pgrid, block, 0, st, v); }
         else {
             timed(KID_POST, [&] { hipLaunchKernelGGL(k_post<false>, grid, block, 0, st, v); });
             hipLaunchKernelGGL(k_decide_balance, one, block, 0, st, v);
