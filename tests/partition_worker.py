@@ -96,6 +96,61 @@ def main():
         assert total == gtotal, (it, total, gtotal)
         assert np.array_equal(xs[mine], xg[mine]), f"sweep {it}: owned rows differ from the global iteration"
         assert np.array_equal(xs[halo], xg[halo]) if len(halo) else True
+    # ---- the window protocol of the fused device path: every rank owns a window with, per source rank,
+    # [2 epoch parities][3 fields][count] slots.  A sweep at epoch e puts the new values of its send lists into field 0,
+    # parity e & 1, of the readers' windows; the all-gather that closes the sweep is the barrier and advances the epoch.
+    # From the second sweep of an approximation on, a row reads its FOREIGN neighbours from its own window, parity
+    # (e - 1) & 1, and never from x; the halo part of x is refreshed once, after the last sweep (k_post / k_halo_copy).
+    # K puts (field 1) of a rank that is already one approximation ahead go to the same parity as the last iterate and
+    # must not disturb it.
+    FIELDS = 3
+    window = {p: np.full((2, FIELDS, len(recv[p])), np.nan) for p in range(world)}
+    pos = {}                                              # foreign node -> (source rank, position in its list)
+    for p in range(world):
+        for k, node in enumerate(recv[p]):
+            pos[int(node)] = (p, k)
+    foreign = np.array([[(int(J[s, i]) in pos) and A[s, i] != 0 for i in mine] for s in range(10)])
+    xg = x0.copy(); xs = x0.copy(); xs[owner != rank] = np.nan
+    for p in range(world):
+        xs[recv[p]] = x0[recv[p]]
+    epoch = 7                                             # any starting epoch
+    def put(field, values_by_peer):
+        par = epoch & 1
+        reqs, bufs = [], {}
+        for p in range(world):
+            if p == rank: continue
+            if len(send[p]): reqs.append(dist.isend(torch.from_numpy(values_by_peer(p).copy()), p))
+            if len(recv[p]):
+                bufs[p] = torch.empty(len(recv[p]), dtype=torch.float64); reqs.append(dist.irecv(bufs[p], p))
+        for r in reqs: r.wait()
+        for p, t in bufs.items(): window[p][par, field] = t.numpy()
+    for approx in range(3):
+        nsweeps = 4 + approx
+        for it in range(nsweeps):
+            xg = jacobi_rows(np.arange(m.n), A, J, b, xg)
+            xin = xs.copy()
+            if it > 0:
+                xin[halo] = np.nan                        # the halo part of x is stale during the sweeps: it must not be read
+            mynew = b[mine].copy()
+            for s in (0, 2, 3, 4, 5, 6, 7, 8, 9, 1):
+                xj = xin[J[s, mine]]
+                if it > 0:
+                    for c in np.flatnonzero(foreign[s]):
+                        p, k = pos[int(J[s, mine[c]])]
+                        xj[c] = window[p][(epoch - 1) & 1, 0, k]
+                mynew -= A[s, mine] * xj
+            xs[mine] = mynew
+            put(0, lambda p: xs[send[p]])
+            dist.barrier(); epoch += 1                    # the sweep's all-gather
+            assert np.array_equal(xs[mine], xg[mine]), f"window protocol, approximation {approx} sweep {it}"
+        par_last = (epoch - 1) & 1
+        dist.barrier(); epoch += 1                        # k_post's all-gather (no puts)
+        put(1, lambda p: -xs[send[p]])                    # a neighbour's next k_props may already put K (field 1) ...
+        for p in range(world):
+            if len(recv[p]): xs[recv[p]] = window[p][par_last, 0]   # ... while the halo of the final iterate is still being copied
+        dist.barrier(); epoch += 1                        # k_props' all-gather
+        dist.barrier(); epoch += 1                        # k_assemble's all-gather
+        assert np.array_equal(xs[halo], xg[halo]) if len(halo) else True
     dist.barrier()
     dist.destroy_process_group()
 
