@@ -102,6 +102,8 @@ struct Ctrl {
     uint32_t stage, approx, iter, iterBudget;
     int32_t cur, hold, best; /* indices into the X pool; best = -1 when none */
     uint32_t linearValid;
+    uint32_t seSource;      /* where Se(H) of the state an attempt starts from already is: 0 nowhere (state came from the host), 1 the Se
+                               array (k_post / k_restore of the accepted step), 2 SeHold (the refused attempt started from the same H) */
     uint32_t epoch;         /* exchange counter, identical on every rank (multi-GPU) */
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
     uint32_t kfEpoch, haloEpoch, haloPar; int32_t haloBuf;   /* multi GPU: which exchange the many-block halo copies (k_halo_copy) belong to */

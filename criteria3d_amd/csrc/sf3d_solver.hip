@@ -387,6 +387,7 @@ __global__ void k_step_begin(Ctrl* c, double maxTimeStep)
 /* a refused attempt restores H = Hold (cpusolver.cpp:182-186) and the loop starts the next one */
 __device__ __forceinline__ void reject_attempt(Ctrl* c)
 {
+    c->seSource = 2;                   /* the next attempt starts from Hold again: its Se is what approximation 0 stored in SeHold */
     c->cur = c->hold;
     begin_attempt(c);
 }
@@ -483,6 +484,7 @@ __device__ __forceinline__ void accept_bookkeeping(Ctrl* c)
     c->curPeriod.sinkSource += c->curStep.sinkSource;
     c->counters[1]++;
     c->acceptDt = c->dt; c->acceptBuf = c->cur;
+    c->seSource = 1;                   /* Se = Se(H accepted): k_post, or k_restore for a restored best step */
     c->stage = ST_ACCEPT;              /* k_accept (flow sums) is the last kernel of the step */
 }
 __device__ __forceinline__ void halve_and_reject(Ctrl* c)
@@ -709,6 +711,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
     const uint32_t wrc = c->wrc;
     const uint32_t par = c->epoch & 1u;
     const bool first = c->approx == 0;
+    const uint32_t seSource = c->seSource;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         const bool mine = !NOT_MINE(v, i);
@@ -719,7 +722,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
             if (i >= v.ns) {
                 const SoilDev s = v.soils[v.cls[i]];
                 double SeH;
-                if (first) { Se = node_se(s, H, z, wrc); SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se; }
+                if (first) {
+                    /* cpusolver.cpp:165-169 recomputes Se(H) at the head of every attempt; the same function of the same H was
+                     * already evaluated by k_post / k_restore (accepted step) or by the refused attempt: reuse those bits */
+                    Se = (seSource == 1) ? v.Se[i] : (seSource == 2) ? v.SeHold[i] : node_se(s, H, z, wrc);
+                    SeH = Se; v.Se[i] = Se; v.SeHold[i] = Se;
+                }
                 else { Se = v.Se[i]; SeH = v.SeHold[i]; }
                 K = mualem_k(s, Se, wrc);
                 const double dThdH = dtheta_dh_cached(s, H, Ho, z, wrc, Se, SeH);
@@ -1897,6 +1905,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpyAsync(v.X[mirror_.cur], m.H.data(), N * 8, hipMemcpyHostToDevice, I.stream));
         HIP_TRY(hipMemcpyAsync(v.Se, m.Se.data(), N * 8, hipMemcpyHostToDevice, I.stream));
         HIP_TRY(hipMemcpyAsync(v.K, m.K.data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        mirror_.seSource = 0; m.ctrlDirty = true;      /* Se now comes from the host's libm: the next attempt recomputes it on the device */
         m.stateDirty = false;
     }
     if (m.sinkDirty) { HIP_TRY(hipMemcpyAsync((void*)v.sink, m.sink.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.sinkDirty = false; }
@@ -1930,6 +1939,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
     }
     if (m.ctrlDirty || ctrlEdited_) {
+        if (mirror_.wrc != p.wrc) mirror_.seSource = 0;      /* another retention curve: the stored Se belongs to the old one */
         fill_params(mirror_, p);
         HIP_TRY(hipMemcpyAsync(v.ctrl, &mirror_, sizeof(Ctrl), hipMemcpyHostToDevice, I.stream));
         m.ctrlDirty = false; ctrlEdited_ = false;
