@@ -1142,13 +1142,32 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
     const uint32_t parLastSweep = (c->epoch - 1u) & 1u;       /* the last sweep put its iterate one epoch ago */
     const double* __restrict__ Xc = v.X[cur];
     double st = 0., sk = 0.;
-    FOR_EACH_CHUNK(v) {
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (NOT_MINE(v, i)) continue;
-        const double H = Xc[i], z = v.z[i];
-        double Se = 1.;
-        if (i >= v.ns) { Se = node_se(v.soils[v.cls[i]], H, z, c->wrc); v.Se[i] = Se; }
-        balance_terms(v, c, i, H, z, Se, st, sk);
+    {   /* software-pipelined chunk loop: the loads of the next chunk (list entry, H, z, class) are issued before the two
+         * pow of the current one - the kernel is latency-bound (VALU 48 % busy), three dependent round trips per chunk */
+        const uint32_t lane_ = threadIdx.x & 63u;
+        const uint32_t wavesTotal_ = gridDim.x * (SF3D_BLOCK / 64);
+        uint32_t li_ = __builtin_amdgcn_readfirstlane(blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6));
+        uint32_t i = 0; double H = 0., z = 0.; uint16_t cl = 0; bool on = false;
+        if (li_ < v.nList) {
+            i = __builtin_amdgcn_readfirstlane(v.chunkList[li_]) * SF3D_CHUNK + lane_;
+            on = !NOT_MINE(v, i);
+            if (on) { H = Xc[i]; z = v.z[i]; cl = v.cls[i]; }
+        }
+        while (li_ < v.nList) {
+            const uint32_t lin = li_ + wavesTotal_;
+            uint32_t i2 = 0; double H2 = 0., z2 = 0.; uint16_t cl2 = 0; bool on2 = false;
+            if (lin < v.nList) {
+                i2 = __builtin_amdgcn_readfirstlane(v.chunkList[lin]) * SF3D_CHUNK + lane_;
+                on2 = !NOT_MINE(v, i2);
+                if (on2) { H2 = Xc[i2]; z2 = v.z[i2]; cl2 = v.cls[i2]; }
+            }
+            if (on) {
+                double Se = 1.;
+                if (i >= v.ns) { Se = node_se(v.soils[cl], H, z, c->wrc); v.Se[i] = Se; }
+                balance_terms(v, c, i, H, z, Se, st, sk);
+            }
+            li_ = lin; i = i2; H = H2; z = z2; cl = cl2; on = on2;
+        }
     }
     const double a = block_sum(st), b = block_sum(sk);
     if (!FUSED) {
