@@ -179,6 +179,8 @@ struct HeatDev {
     sf3d_d2* hA2;                                   /* [5][N] normalised off-diagonals (slots paired like A2); 0 where the slot is no heat link */
     const double* hdist;                            /* [10][N] nodeDistance3D of every link between two soil nodes */
     /* per-node conductivities evaluated once per node instead of once per link end (same arguments => same bits) */
+    const double* airP;                             /* [N] computePressure_fromAltitude(z): a pow of a static input, evaluated once per node */
+    double* thetaOld;                               /* [N] theta(Hold - z): constant over the heat sub-steps of one water step */
     double *kHeat, *kIsoVap, *hAvg;                 /* heat process: Campbell conductivity, isothermal vapour conductivity at (T, mean h); mean h */
     double *wThLiq, *wThVap, *wTm;                  /* water process: thermal liquid / vapour conductivity at (mean T, H - z); mean T */
     /* atmosphere boundary (HeatSurface nodes) and fixed-temperature boundary, full-length arrays */

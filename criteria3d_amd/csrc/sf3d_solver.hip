@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_pro
                     if (hv.vapor) {
                         K += h_isothermal_vapor_conductivity(s, Tm, h, theta) * (H_G / H_RHOW);
                         C += v.size[i] * h_dthetav_dh(s, h, Tm, dThdH, wrc);
-                        hv.wThVap[i] = h_thermal_vapor_conductivity(s, z, Tm, h, theta);
+                        hv.wThVap[i] = h_thermal_vapor_conductivity(s, hv.airP[i], Tm, h, theta);
                     }
                     hv.wTm[i] = Tm;
                     hv.wThLiq[i] = h_thermal_liquid_conductivity(Tm - H_ZEROC, h, K);
@@ -1425,6 +1425,7 @@ struct DeviceSolver::Impl {
     std::vector<uint32_t> gsLevelStart;    /* SF3D_HEAT_GS=1: level l = gsOrder[gsLevelStart[l] .. gsLevelStart[l+1]) */
     uint32_t lastHeatSteps = 1;            /* heat steps (accepted + halved) of the previous computeStep: look-ahead depth */
     double* heatOut[6] = {nullptr};       /* bAero, bSoilCond, bSens, bLat, bRad, bAdv (device) */
+    double* heatAirP = nullptr;            /* filled by k_heat_static once z is on the device */
     /* hipGraph cache: one instantiated graph per (with head part, number of queued sweeps) */
     std::vector<std::pair<uint32_t, hipGraphExec_t>> graphs;
     int useFused = -1;                     /* SF3D_FUSED_DECIDE=0 keeps the separate decision kernel */
@@ -1811,6 +1812,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         v.lto = lto; v.lkind = lkind; v.larea = larea; v.ldist = ldist; v.soils = soils; v.roughness = roughness;
         v.cdesc = dcdesc;
 
+        I.heatAirP = nullptr;
         if (m.heat) {       /* coupled heat transport: state, system, per-node conductivities, boundary and link flux arrays */
             HeatDev& hv = v.heat;
             hv = HeatDev{};
@@ -1824,6 +1826,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             HIP_TRY(alloc0(hv.hC, N)); HIP_TRY(alloc0(hv.hcapTerm, N)); HIP_TRY(alloc0(hv.hb, N)); HIP_TRY(alloc0(hv.hD, N));
             HIP_TRY(dev_alloc(I.allocs, hv.hA2, NS / 2)); HIP_TRY(hipMemset(hv.hA2, 0, NS * 8));
             HIP_TRY(alloc0(hv.kHeat, N)); HIP_TRY(alloc0(hv.kIsoVap, N)); HIP_TRY(alloc0(hv.hAvg, N));
+            HIP_TRY(alloc0(hv.thetaOld, N));
+            HIP_TRY(alloc0(tmp, N)); hv.airP = tmp; I.heatAirP = tmp;
             HIP_TRY(alloc0(hv.wThLiq, N)); HIP_TRY(alloc0(hv.wThVap, N)); HIP_TRY(alloc0(hv.wTm, N));
             const double** inputs[9] = {&hv.bHeightWind, &hv.bHeightT, &hv.bRoughH, &hv.bT, &hv.bRH, &hv.bWind, &hv.bNetIrr, &hv.bFixT, &hv.bFixDepth};
             for (auto* pp : inputs) { HIP_TRY(alloc0(tmp, N)); *pp = tmp; }
@@ -1907,6 +1911,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemset(v.A2, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
         HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8)); HIP_TRY(hipMemset(v.SeHold, 0, N * 8));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(hipMemset(v.X[k], 0, N * 8));
+        if (m.heat && I.heatAirP) hipLaunchKernelGGL(k_heat_static, dim3(v.nb), dim3(SF3D_BLOCK), 0, 0, v, I.heatAirP);
         HIP_TRY(hipDeviceSynchronize());      /* null-stream fills must land before the (non-blocking) solver stream runs */
 
         std::memset(&mirror_, 0, sizeof(mirror_));
