@@ -130,10 +130,12 @@ HEAT_SCALARS = ("total_water", "storage", "heat_storage", "heat_mbr", "heat_mbe"
 FLUX_TYPES = 9
 
 
-def _heat_hours(sf, m, heat, plan, threads=1, use_period=False, flux_nodes=()):
+def _heat_hours(sf, m, heat, plan, threads=1, use_period=False, flux_nodes=(), pre=None):
     """plan: list of (rain_mm, keep_arrays).  Hourly atmosphere from cm.heat_forcing(h)."""
     sf.lib.sf3d_reset_solver_state()
     cm.build(sf, m, threads=threads, heat=heat)
+    if pre is not None:
+        pre(sf, m)
     hs = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE)
     soil = np.arange(m.ns, m.n)
     out, scal = {}, {k: [] for k in HEAT_SCALARS}
@@ -208,6 +210,21 @@ def heat_catchment_latent(sf, threads=1):
                        threads, flux_nodes=(mid, mid + m.ns))
 
 
+def _water_table_pre(sf, m):
+    last = m.n - 1
+    sf.check(sf.lib.sf3d_set_node_prescribed_total_potential(last, float(m.z[last]) + 0.1), "prescribed")
+    sf.check(sf.lib.sf3d_set_node_boundary_fixed_temperature(last, 284.15, 0.3), "fixed temperature")
+
+
+def heat_water_table(sf, threads=1):
+    """PrescribedTotalWaterPotential at the bottom (a water table 10 cm above the last node) carrying the fixed-temperature
+    boundary instead of FreeDrainage: capillary rise against evaporation at the top, conduction to the fixed temperature"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    m.btype[m.n - 1] = capi.BND_PRESCRIBED
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=True, save_mode=1), [(0.0, h in (0, 4)) for h in range(5)], threads,
+                       flux_nodes=(20, 21), pre=_water_table_pre)
+
+
 def heat_advection_steps(sf, threads=1):
     """advective heat flux switched on (initializeHeatFlag(All, true, true)): the reference multiplies the ROW-NORMALISED
     water coefficient into its link water fluxes (quirk 1), the advective term is orders of magnitude too large and the
@@ -248,6 +265,7 @@ SCENARIOS = {
     "heat_column_period": heat_column_period,
     "heat_catchment_latent": heat_catchment_latent,
     "heat_advection_steps": heat_advection_steps,
+    "heat_water_table": heat_water_table,
 }
 HEAT_SCENARIOS = tuple(k for k in SCENARIOS if k.startswith("heat_"))
 
