@@ -95,3 +95,28 @@ def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
         assert set(a.files) == set(b.files)
         for k in a.files:
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_ravone_dem_first_steps_match_oracle(product, oracle):
+    """BASELINE config 5's grid at full size: the Ravone DEM (422 282 valid cells of 4 m, 14 soil layers of varying depth,
+    5.09 M nodes, irregular outline) through product and oracle for the first computeStep calls of a 20 mm/h hour - mixed
+    chunk descriptors (holes, short columns) at scale."""
+    from pathlib import Path
+    from criteria3d_amd import esri
+    dem, _ = esri.load_dem_fixture(Path(__file__).resolve().parent / "golden" / "ravone_dem_519x1208.npz")
+    m = cm.dem_model_fast(dem)
+    assert m.n > 5_000_000
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=64)
+    gs, gd = cm.run_hour(product, m, 20.0, max_steps=4)
+    os_, od = cm.run_hour(oracle, m, 20.0, max_steps=4)
+    np.testing.assert_allclose(gd, od, rtol=1e-12)
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6
+    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6
+    assert abs(g["storage"] - o["storage"]) <= 1e-6 * abs(o["storage"])
+    gc, oc = product.counters(), oracle.counters()
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
