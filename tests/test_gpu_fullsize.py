@@ -120,3 +120,26 @@ def test_ravone_dem_first_steps_match_oracle(product, oracle):
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+def test_ravone_dem_coupled_heat_first_step(product, oracle):
+    """the same grid with coupled heat transport (BASELINE config 5): one computeStep - a 600 s water step and its two heat
+    steps - on 5.09 M nodes, every top soil cell an atmosphere boundary.  (The oracle runs its loops on 64 threads here; the
+    first step has no ponded water, so the reference's racy ponded-evaporation write is not reached.)"""
+    from pathlib import Path
+    from criteria3d_amd import esri
+    dem, _ = esri.load_dem_fixture(Path(__file__).resolve().parent / "golden" / "ravone_dem_519x1208.npz")
+    m = cm.with_heat_surface(cm.dem_model_fast(dem))
+    heat = cm.Heat(water=True, latent=True, save_mode=0)
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=64, heat=heat)
+        cm.apply_heat_forcing(sf, m, 0)
+    _, gd = cm.run_hour(product, m, 2.0, max_steps=1)
+    _, od = cm.run_hour(oracle, m, 2.0, max_steps=1)
+    np.testing.assert_allclose(gd, od, rtol=1e-12)
+    gT, oT = product.temperature(0, m.n)[m.ns:], oracle.temperature(0, m.n)[m.ns:]
+    gH, oH = product.total_potential(0, m.n), oracle.total_potential(0, m.n)
+    assert np.max(np.abs(gT - oT) / oT) < 1e-6
+    assert np.max(np.abs(gH - oH) / np.maximum(np.abs(oH), 1e-9)) < 1e-6
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
