@@ -27,6 +27,9 @@ elif case == "het":
     m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
 elif case == "ragged":
     m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
+elif case == "ravone":
+    from criteria3d_amd import esri
+    m, plan = cm.dem_model_fast(esri.load_dem_fixture(Path(__file__).resolve().parent.parent / "tests" / "golden" / "ravone_dem_519x1208.npz")[0]), [(20.0, 3)]
 elif case == "random":
     m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
 elif case == "heat":
@@ -36,9 +39,10 @@ else:
 heat = cm.Heat(water=True, latent=True, save_mode=0) if case == "heat" else None
 # a throw-away model first: re-initialisation must drop the windows, re-export and re-connect
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
-cm.run_hour(sf, m, 5.0, max_steps=2)
-sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+if case != "ravone":
+    cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
+    cm.run_hour(sf, m, 5.0, max_steps=2)
+    sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
 owner = sf.owner_map(world, m.n)
 res = {"owner": owner}

@@ -43,12 +43,15 @@ def oracle_reference(oracle, case):
         m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
     elif case == "het":
         m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
+    elif case == "ravone":
+        from criteria3d_amd import esri
+        m, plan = cm.dem_model_fast(esri.load_dem_fixture(ROOT / "tests" / "golden" / "ravone_dem_519x1208.npz")[0]), [(20.0, 3)]
     elif case == "random":
         m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
     else:
         m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
     oracle.lib.sf3d_reset_solver_state()
-    cm.build(oracle, m, threads=1)
+    cm.build(oracle, m, threads=64 if case == "ravone" else 1)
     out = []
     for item in plan:
         mm, mx = item if isinstance(item, tuple) else (item, None)
@@ -57,7 +60,8 @@ def oracle_reference(oracle, case):
     return m, out
 
 
-@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614), (3, "random", 29615)])
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614), (3, "random", 29615),
+                                             (4, "ravone", 29616)])      # the real 5.09 M-node DEM cut into four strips
 def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
     ranks = run_ranks(world, case, tmp_path, port)
     m, ref = oracle_reference(oracle, case)
