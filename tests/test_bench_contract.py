@@ -1,0 +1,30 @@
+"""The one JSON line bench.py prints is a contract with the driver: this checks the committed line of the last profiled
+run (profiles/*_bench.json, produced by `python bench.py` on an MI355X) for every field the contract names."""
+import glob
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_committed_bench_line_has_every_contract_field():
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r01_*_bench.json")))
+    assert files, "no committed bench line under profiles/"
+    line = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["metric"].startswith("simulated-hours/sec on 512x512x20") and line["unit"] == "sim-h/s"
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["dtype"] == "f64" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+    assert abs(line["value"] - line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.5 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["unit"] == "sim-h/s" and c["cores"] >= 1 and c["value"] > 0
