@@ -28,3 +28,23 @@ def test_committed_bench_line_has_every_contract_field():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["unit"] == "sim-h/s" and c["cores"] >= 1 and c["value"] > 0
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_runs_and_prints_one_json_line():
+    """a short real run (C2, one simulated hour, CPU baseline on a 3 s budget): exactly one JSON line on stdout"""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "C2", "--steps", "1", "--warmup", "1", "--cpu-budget", "3"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 1 and line["warmup"] == 1 and line["value"] > 0
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["kernel"] == "k_sweep"
+    assert line["cpu_baseline"] is not None and line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["value"] > 0
+    assert line["config"]["work"]["accepted"] == 22          # C2 F20 hour 0 (SURVEY.md 8c)
