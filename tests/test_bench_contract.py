@@ -48,3 +48,22 @@ def test_bench_runs_and_prints_one_json_line():
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["kernel"] == "k_sweep"
     assert line["cpu_baseline"] is not None and line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["value"] > 0
     assert line["config"]["work"]["accepted"] == 22          # C2 F20 hour 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu():
+    """the launch the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with both ranks on the
+    one GPU of the test box (SF3D_BENCH_SHARE_GPU=1: gloo control plane, same device-side exchange)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SF3D_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["work"]["accepted"] == 22
