@@ -77,6 +77,38 @@ __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b 
 extern "C" __device__ double __ocml_powr_f64(double, double);
 __device__ __forceinline__ double ppow(double x, double y) { return __ocml_powr_f64(x, y); }
 
+/* log for the logarithmic mean: table-driven, < 0.6 ulp, ~30 VALU instructions against ~100 of the device library's
+ * 1-ulp routine (sf3d_fastmath.inc; the host build of the same text is checked against mpmath and libm, and the device
+ * against the host build bit for bit).  -DSF3D_FAST_LOG=0 restores the library call. */
+#ifndef SF3D_FAST_LOG
+#define SF3D_FAST_LOG 1
+#endif
+#define SF3D_FM_FN __device__ __forceinline__
+#define SF3D_FM_TABLE __device__ const
+/* the 128-piece table lives in LDS (3 KB, structure of arrays): every kernel that evaluates flog() calls flog_init() first */
+struct FlogLds { double invc[128], hi[128], lo[128]; };
+__device__ __forceinline__ FlogLds& flog_lds() { __shared__ FlogLds t; return t; }
+#define SF3D_FM_LOOKUP(i, e) struct sf3d_flog_entry e; { const FlogLds& t_ = flog_lds(); e.invc = t_.invc[i]; e.logc_hi = t_.hi[i]; e.logc_lo = t_.lo[i]; }
+#include "sf3d_fastmath.inc"
+__device__ __forceinline__ void flog_init()
+{
+#if SF3D_FAST_LOG
+    FlogLds& t = flog_lds();
+    for (uint32_t k = threadIdx.x; k < SF3D_FLOG_N; k += blockDim.x) {
+        t.invc[k] = sf3d_flog_table[k].invc; t.hi[k] = sf3d_flog_table[k].logc_hi; t.lo[k] = sf3d_flog_table[k].logc_lo;
+    }
+    __syncthreads();
+#endif
+}
+__device__ __forceinline__ double flog(double x)
+{
+#if SF3D_FAST_LOG
+    return sf3d_flog(x);
+#else
+    return log(x);
+#endif
+}
+
 __device__ __forceinline__ int free_buffer(const Ctrl* c)
 {
     for (int b = 0; b < SF3D_POOL; ++b)
@@ -120,11 +152,19 @@ __device__ __forceinline__ double reduce_partials_max(const double* p, uint32_t 
 }
 
 /* ---- Math::computeMean (otherFunctions.cpp:7-36) ---- */
+/* mean_of: library log (kernels that evaluate a handful of means); mean_of_fast: the table-driven log - only inside kernels
+ * that have called flog_init() (the two assembly kernels, where the logarithm is ~70 % of the arithmetic) */
 __device__ __forceinline__ double mean_of(double v1, double v2, uint32_t type)
 {
     if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
     if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
     return (v1 == v2) ? v1 : (v1 - v2) / log(v1 / v2);
+}
+__device__ __forceinline__ double mean_of_fast(double v1, double v2, uint32_t type)
+{
+    if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
+    if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
+    return (v1 == v2) ? v1 : (v1 - v2) / flog(v1 / v2);
 }
 
 /* ---- Soil:: (soilPhysics.cpp) ---- */
@@ -698,11 +738,14 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
 
 /* computeCapacity (water.cpp:279-297) + step-begin Se (cpusolver.cpp:165-169) +
  * updateBoundaryWaterData (water.cpp:632-807) */
+#ifndef SF3D_PROPS_HEAT_WAVES
+#define SF3D_PROPS_HEAT_WAVES 2
+#endif
 #ifndef SF3D_PROPS_WAVES
 #define SF3D_PROPS_WAVES 4     /* 128 VGPRs, 20 B of scratch: 236 -> 214 us at C4; 5 waves (95 VGPRs, 148 B scratch) gives the same */
 #endif
 template <int MODE, bool HEAT>
-__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_PROPS_WAVES) k_props(DevView v)
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_PROPS_HEAT_WAVES : SF3D_PROPS_WAVES) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
@@ -802,6 +845,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_halo_copy(DevView v)
 }
 
 /* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
+/* FAST: table-driven log in the mean (soil rows); the surface rows keep the library call - their ten-way link dispatch is
+ * already at the register limit and evaluates one mean per node */
+template <bool FAST>
 __device__ __forceinline__ double infiltration_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t j, size_t e,
                                                            const double* __restrict__ Xc, const double* __restrict__ Xh,
                                                            double Hi, double Hoi, double zi)
@@ -831,7 +877,7 @@ __device__ __forceinline__ double infiltration_conductance(const DevView& v, con
     if (maxInfRate < 2.78e-11) return 0.;
     const double dH = dmax(surfH - soilH, 1e-12);
     const double maxK = maxInfRate * (dist / dH);
-    const double meanK = mean_of(s.Ksat, v.K[so], c->meanType);
+    const double meanK = FAST ? mean_of_fast(s.Ksat, v.K[so], c->meanType) : mean_of(s.Ksat, v.K[so], c->meanType);
     return (dmin(factor * meanK, maxK) * area) / dist;
 }
 
@@ -872,7 +918,7 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
         courant = dmax(courant, vel * dt / dist);
         return Kij;
     }
-    return infiltration_conductance(v, c, i, j, e, Xc, Xh, Hi, Hoi, zi);
+    return infiltration_conductance<false>(v, c, i, j, e, Xc, Xh, Hi, Hoi, zi);
 }
 
 /* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
@@ -883,10 +929,10 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
 __device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i, uint32_t j, double area, double dist3, double& inv)
 {
     const double Ti = hv.wTm[i], Tj = hv.wTm[j];
-    const double avgL = mean_of(hv.wThLiq[i], hv.wThLiq[j], SF3D_MEAN_LOGARITHMIC);
+    const double avgL = mean_of_fast(hv.wThLiq[i], hv.wThLiq[j], SF3D_MEAN_LOGARITHMIC);
     inv += (avgL * (Tj - Ti) / dist3) * area;
     if (hv.vapor) {
-        const double avgV = mean_of(hv.wThVap[i], hv.wThVap[j], SF3D_MEAN_LOGARITHMIC);
+        const double avgV = mean_of_fast(hv.wThVap[i], hv.wThVap[j], SF3D_MEAN_LOGARITHMIC);
         inv += ((avgV * (Tj - Ti) / dist3) * area) / H_RHOW;
     }
 }
@@ -950,6 +996,12 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 /* rows of the soil-only chunks [qSplit, nChunks).  Two groups of five slots: all index / area /
  * distance loads and neighbour-K gathers of a group are issued before its first logarithm, so
  * ~20 loads per lane overlap instead of forming dependent round trips (4 waves/SIMD). */
+#ifndef SF3D_ASM_HEAT_WAVES
+#define SF3D_ASM_HEAT_WAVES 2
+#endif
+#ifndef SF3D_ASM_SCHED_BARRIER
+#define SF3D_ASM_SCHED_BARRIER 1
+#endif
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
@@ -996,16 +1048,20 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 double ks = 0.;
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
-                    ks = (mean_of(ki, kn, meanType) * area[t]) / dist[t];
+                    ks = (mean_of_fast(ki, kn, meanType) * area[t]) / dist[t];
                 } else if (kd[t] == LK_SOIL_VERT) {
-                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dist[t];
+                    ks = (mean_of_fast(Ki, kj[t], meanType) * area[t]) / dist[t];
                 } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
-                    ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
+                    ks = infiltration_conductance<true>(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
                 }                                                            /* a soil row has no runoff link */
                 if (HEAT && (kd[t] == LK_SOIL_LAT || kd[t] == LK_SOIL_VERT))
                     add_thermal_fluxes(v.heat, i, j[t], area[t], v.heat.hdist[(size_t)s * v.N + i], invFlux);
                 k[s] = ks;
                 sum += ks;
+#if SF3D_ASM_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);      /* one link's divide -> log -> divide chain at a time: the scheduler would
+                                                         * otherwise interleave the five of a group and run out of registers */
+#endif
             }
         }
         store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
@@ -1016,9 +1072,10 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
  * blocks [nbSurf, nbSurf + nbSoil) the soil rows.  FUSED: the block that arrives last takes the
  * Courant decision (checkCourant) instead of a separate one-block kernel. */
 template <bool FUSED, bool NT, bool HEAT>
-__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? 2 : SF3D_ASM_WAVES) k_assemble(DevView v)
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
+    flog_init();
     double bm = 0.;
     if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT>(v, blockIdx.x, v.nbSurf);
     else assemble_soil_rows<NT, HEAT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
@@ -2120,6 +2177,29 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
     HIP_TRY(hipStreamSynchronize(I.stream));
     mirror_ = *I.hostCtrl;
     *out = mirror_.query[0];
+    return SF3D_OK;
+}
+
+__global__ void k_device_log(const double* x, double* y, uint32_t n)
+{
+    flog_init();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = flog(x[i]);
+}
+
+/* test hook: the link kernels' logarithm on host values */
+sf3d_error_t DeviceSolver::device_log(uint32_t n, const double* x, double* out)
+{
+    if (n == 0) return SF3D_OK;
+    double *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_device_log, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dx));
+    HIP_TRY(hipFree(dy));
     return SF3D_OK;
 }
 

@@ -1,0 +1,9 @@
+/* host build of criteria3d_amd/csrc/sf3d_fastmath.inc (same text as the device compiles) for tests/test_fastmath.py */
+#include <math.h>
+#include <stddef.h>
+#define SF3D_FM_FN static inline
+#define SF3D_FM_TABLE static const
+#include "sf3d_fastmath.inc"
+
+void fm_log(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = sf3d_flog(x[i]); }
+void fm_log_libm(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = log(x[i]); }
