@@ -71,31 +71,34 @@ template <bool NT, class T> __device__ __forceinline__ void store_stream(T* p, T
 __device__ __forceinline__ double dmax(double a, double b) { return (a < b) ? b : a; }
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
 
-/* pow with a base that is never negative here (saturation degrees, alpha*psi, 1 + t): ocml's powr is the same core
- * without the sign / integer-exponent handling - bit-identical to pow on 4 M samples of the soil functions' ranges
- * (scripts/experiments/powr_probe.cpp) and ~6 % cheaper */
-extern "C" __device__ double __ocml_powr_f64(double, double);
-__device__ __forceinline__ double ppow(double x, double y) { return __ocml_powr_f64(x, y); }
-
-/* log for the logarithmic mean: table-driven, < 0.6 ulp, ~30 VALU instructions against ~100 of the device library's
- * 1-ulp routine (sf3d_fastmath.inc; the host build of the same text is checked against mpmath and libm, and the device
- * against the host build bit for bit).  -DSF3D_FAST_LOG=0 restores the library call. */
+/* ---- log and pow of the hot kernels: table-driven routines of sf3d_fastmath.inc ----
+ * The device library's log / pow are ~90 / ~230 VALU instructions at 1 ulp; the table designs need ~45 / ~85 at 0.51 ulp
+ * (measured against mpmath), i.e. they agree with the reference's libm in 99.9 % of the cases instead of most.  The host
+ * build of the same text is checked against mpmath and libm (tests/test_fastmath.py) and the device against the host
+ * build bit for bit (tests/test_gpu_fastmath.py).  The tables (128 pieces of log, 128 of 2^(j/128): 5 KB) sit in LDS:
+ * 64 lanes with 64 different pieces would cost ~64 texture-addresser cycles per vector-memory gather.  Every kernel that
+ * evaluates flog() / ppow() calls fm_init() first.  -DSF3D_FAST_LOG=0 / -DSF3D_FAST_POW=0 restore the library calls
+ * (pow: ocml's powr, the base is never negative here: saturation degrees, alpha*psi, 1 + t). */
 #ifndef SF3D_FAST_LOG
 #define SF3D_FAST_LOG 1
 #endif
+#ifndef SF3D_FAST_POW
+#define SF3D_FAST_POW 1
+#endif
 #define SF3D_FM_FN __device__ __forceinline__
 #define SF3D_FM_TABLE __device__ const
-/* the 128-piece table lives in LDS (3 KB, structure of arrays): every kernel that evaluates flog() calls flog_init() first */
-struct FlogLds { double invc[128], hi[128], lo[128]; };
-__device__ __forceinline__ FlogLds& flog_lds() { __shared__ FlogLds t; return t; }
-#define SF3D_FM_LOOKUP(i, e) struct sf3d_flog_entry e; { const FlogLds& t_ = flog_lds(); e.invc = t_.invc[i]; e.logc_hi = t_.hi[i]; e.logc_lo = t_.lo[i]; }
+struct FmLds { double invc[128], lhi[128], llo[128], ehi[128], elo[128]; };
+__device__ __forceinline__ FmLds& fm_lds() { __shared__ FmLds t; return t; }
+#define SF3D_FM_LOOKUP(i, e) struct sf3d_flog_entry e; { const FmLds& t_ = fm_lds(); e.invc = t_.invc[i]; e.logc_hi = t_.lhi[i]; e.logc_lo = t_.llo[i]; }
+#define SF3D_FM_EXP_LOOKUP(j, e) struct sf3d_fexp_entry e; { const FmLds& t_ = fm_lds(); e.hi = t_.ehi[j]; e.lo = t_.elo[j]; }
 #include "sf3d_fastmath.inc"
-__device__ __forceinline__ void flog_init()
+__device__ __forceinline__ void fm_init()
 {
-#if SF3D_FAST_LOG
-    FlogLds& t = flog_lds();
-    for (uint32_t k = threadIdx.x; k < SF3D_FLOG_N; k += blockDim.x) {
-        t.invc[k] = sf3d_flog_table[k].invc; t.hi[k] = sf3d_flog_table[k].logc_hi; t.lo[k] = sf3d_flog_table[k].logc_lo;
+#if SF3D_FAST_LOG || SF3D_FAST_POW
+    FmLds& t = fm_lds();
+    for (uint32_t k = threadIdx.x; k < 128; k += blockDim.x) {
+        t.invc[k] = sf3d_flog_table[k].invc; t.lhi[k] = sf3d_flog_table[k].logc_hi; t.llo[k] = sf3d_flog_table[k].logc_lo;
+        t.ehi[k] = sf3d_fexp_table[k].hi; t.elo[k] = sf3d_fexp_table[k].lo;
     }
     __syncthreads();
 #endif
@@ -106,6 +109,15 @@ __device__ __forceinline__ double flog(double x)
     return sf3d_flog(x);
 #else
     return log(x);
+#endif
+}
+extern "C" __device__ double __ocml_powr_f64(double, double);
+__device__ __forceinline__ double ppow(double x, double y)
+{
+#if SF3D_FAST_POW
+    return sf3d_fpow(x, y);
+#else
+    return __ocml_powr_f64(x, y);
 #endif
 }
 
@@ -742,13 +754,15 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
 #define SF3D_PROPS_HEAT_WAVES 2
 #endif
 #ifndef SF3D_PROPS_WAVES
-#define SF3D_PROPS_WAVES 4     /* 128 VGPRs, 20 B of scratch: 236 -> 214 us at C4; 5 waves (95 VGPRs, 148 B scratch) gives the same */
+#define SF3D_PROPS_WAVES 5     /* 96 VGPRs, no scratch on one GPU (the table-driven pow needs fewer registers than the library's):
+                                * 150 -> 135 us at C4 against 4 waves, launched with exactly the 1 280 resident blocks */
 #endif
 template <int MODE, bool HEAT>
 __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_PROPS_HEAT_WAVES : SF3D_PROPS_WAVES) k_props(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_APPROX) return;
+    fm_init();
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
     const uint32_t wrc = c->wrc;
@@ -1075,7 +1089,7 @@ template <bool FUSED, bool NT, bool HEAT>
 __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
-    flog_init();
+    fm_init();
     double bm = 0.;
     if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT>(v, blockIdx.x, v.nbSurf);
     else assemble_soil_rows<NT, HEAT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
@@ -1190,11 +1204,15 @@ __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, u
 
 /* cpusolver.cpp:451-457 (H = x is implicit: H is the current pool buffer) + the two sums of
  * computeCurrentMassBalance (water.cpp:71-90, 130-140) */
+#ifndef SF3D_POST_WAVES
+#define SF3D_POST_WAVES 8      /* 64 VGPRs: all 2 048 blocks of the grid resident at once (at 70 VGPRs 1 792 are, and the rest form a tail) */
+#endif
 template <bool FUSED>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_post(DevView v)
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_POST_WAVES) k_post(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_POST) return;
+    fm_init();
     const int cur = c->cur;
     const uint32_t parLastSweep = (c->epoch - 1u) & 1u;       /* the last sweep put its iterate one epoch ago */
     const double* __restrict__ Xc = v.X[cur];
@@ -1249,6 +1267,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_RESTORE) return;
+    fm_init();
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
     const uint32_t par = c->epoch & 1u;
@@ -1497,6 +1516,7 @@ struct DeviceSolver::Impl {
     uint32_t pushBlocks = 0;
     /* timing */
     int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
+    uint32_t propsBlocks = 0;             /* grid of the single-GPU k_props: the blocks resident at once */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -2182,9 +2202,15 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
 
 __global__ void k_device_log(const double* x, double* y, uint32_t n)
 {
-    flog_init();
+    fm_init();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = flog(x[i]);
+}
+__global__ void k_device_pow(const double* x, const double* e, double* y, uint32_t n)
+{
+    fm_init();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = ppow(x[i], e[i]);
 }
 
 /* test hook: the link kernels' logarithm on host values */
@@ -2200,6 +2226,24 @@ sf3d_error_t DeviceSolver::device_log(uint32_t n, const double* x, double* out)
     HIP_TRY(hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(dx));
     HIP_TRY(hipFree(dy));
+    return SF3D_OK;
+}
+
+sf3d_error_t DeviceSolver::device_pow(uint32_t n, const double* x, const double* y, double* out)
+{
+    if (n == 0) return SF3D_OK;
+    double *dx = nullptr, *dy = nullptr, *dz = nullptr;
+    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dz, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_device_pow, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, dz, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dz, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(dx));
+    HIP_TRY(hipFree(dy));
+    HIP_TRY(hipFree(dz));
     return SF3D_OK;
 }
 
@@ -2271,6 +2315,16 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     std::memcpy(atStart, mirror_.counters, sizeof(atStart));
     int guard = 0;
 
+    /* k_props on one GPU: exactly as many blocks as are resident at once (equal work per block, no tail round) */
+    if (I.propsBlocks == 0) {
+        int perCu = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_props<0, false>, SF3D_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
+        I.propsBlocks = SF3D_MAX_BLOCKS;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            I.propsBlocks = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;
+        if (const char* e = getenv("SF3D_PROPS_BLOCKS")) if (atoi(e) > 0) I.propsBlocks = (uint32_t)atoi(e);
+    }
+    const dim3 propsGrid(v.nb < I.propsBlocks ? v.nb : I.propsBlocks);
     /* one approximation's worth of guarded kernels */
     auto enqueue_props = [&] {
             if (heatOn && multi) {      /* sharded heat always uses the fused exchange; halo conductivities are recomputed locally */
@@ -2280,7 +2334,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
             else if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
             else if (multi && fusedMulti) { timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); }); hipLaunchKernelGGL(k_halo_copy<0>, pgrid, block, 0, st, v); }
-            else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), grid, block, 0, st, v); });
+            else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), propsGrid, block, 0, st, v); });
             if (multi && !fusedMulti) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);

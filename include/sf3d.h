@@ -349,9 +349,11 @@ const char*  sf3d_kernel_name(int k);
 /* launches, total milliseconds and nodes processed per launch of kernel k since timing was
  * enabled (drains the event pool) */
 sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint64_t* nodes_per_launch);
-/* Test hook: the logarithm the link kernels use for the logarithmic mean (a table-driven routine) evaluated on
+/* Test hooks: the logarithm the link kernels use for the logarithmic mean (a table-driven routine) evaluated on
  * the device for `count` host values; tests compare it bit for bit with the host build of the same source. */
 sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out);
+/* the same for the pow of the soil-property kernels: out[k] = x[k]^y[k], x >= 0 */
+sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out);
 
 /* ---- multi-GPU: one process per GPU, row strips of surface-cell columns ------
  * Every rank builds the SAME global model through the setters above; the library computes only the

@@ -7,7 +7,7 @@ from criteria3d_amd import capi
 
 import sys, os
 sys.path.insert(0, os.path.dirname(__file__))
-from test_fastmath import fm, samples  # noqa: F401  (fixture)
+from test_fastmath import fm, pow_samples, samples  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -25,3 +25,20 @@ def test_device_log_special_values(product):
     y = np.empty_like(x)
     product.check(product.lib.sf3d_device_log(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd)), "device_log")
     assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == np.inf and np.isnan(y[3]) and abs(y[4] - np.log(5e-324)) < 1e-12 and y[5] == 0.0
+
+
+def test_device_pow_equals_host_build(product, fm):  # noqa: F811
+    for name, (x, y) in pow_samples(seed=7, n=1_000_000).items():
+        x, y = np.ascontiguousarray(x), np.ascontiguousarray(y)
+        out = np.empty_like(x)
+        product.check(product.lib.sf3d_device_pow(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd), out.ctypes.data_as(capi.pd)), "device_pow")
+        assert np.array_equal(out.view(np.int64), fm("fm_pow", x, y).view(np.int64)), name
+
+
+def test_device_pow_special_values(product, fm):  # noqa: F811
+    bases = np.array([0.0, 1.0, np.inf, np.nan, 5e-324, 1e-310, 0.5, 2.0, 1e300, 1e-300])
+    exps = np.array([0.0, np.inf, -np.inf, np.nan, 2.5, -2.5, 1.0, 1e300, -1e300])
+    x, y = [np.ascontiguousarray(a.ravel()) for a in np.meshgrid(bases, exps)]
+    out = np.empty_like(x)
+    product.check(product.lib.sf3d_device_pow(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd), out.ctypes.data_as(capi.pd)), "device_pow")
+    assert np.array_equal(out, fm("fm_pow", x, y), equal_nan=True)
