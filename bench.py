@@ -237,7 +237,7 @@ def main():
     # cannot collect counters itself
     traffic = None
     try:
-        prof = json.load(open(ROOT / "profiles" / "r01_j_kernel_summary.json"))
+        prof = json.load(open(ROOT / "profiles" / "r01_k_kernel_summary.json"))
         if world == 1 and args.workload == "C4" and dom in prof and "hbm_traffic_MB" in prof[dom]:
             traffic = prof[dom]["hbm_traffic_MB"] * 1e6
     except Exception:  # noqa: BLE001

@@ -1516,7 +1516,8 @@ struct DeviceSolver::Impl {
     uint32_t pushBlocks = 0;
     /* timing */
     int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
-    uint32_t propsBlocks = 0;             /* grid of the single-GPU k_props: the blocks resident at once */
+    std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
+    int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -2276,6 +2277,24 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool multi = world_ > 1;
     const bool heatOn = v.heat.on != 0;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
+    if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
+    /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
+     * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
+     * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
+    auto resident = [&](const void* fn) -> dim3 {
+        uint32_t nbk = 0;
+        for (auto& r : I.residentBlocks) if (r.first == fn) nbk = r.second;
+        if (nbk == 0) {
+            int perCu = 0, dev = 0; hipDeviceProp_t prop;
+            nbk = SF3D_MAX_BLOCKS;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, SF3D_BLOCK, 0) == hipSuccess && perCu > 0
+                && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                nbk = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;
+            if (I.residentGrids == 0) nbk = SF3D_MAX_BLOCKS;
+            I.residentBlocks.push_back({fn, nbk});
+        }
+        return dim3(v.nb < nbk ? v.nb : nbk);
+    };
     if (heatOn && multi) I.useFused = 1;       /* the sharded heat step exists only in the fused-exchange form */
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
@@ -2315,16 +2334,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     std::memcpy(atStart, mirror_.counters, sizeof(atStart));
     int guard = 0;
 
-    /* k_props on one GPU: exactly as many blocks as are resident at once (equal work per block, no tail round) */
-    if (I.propsBlocks == 0) {
-        int perCu = 0, dev = 0; hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_props<0, false>, SF3D_BLOCK, 0) != hipSuccess || perCu <= 0) perCu = 4;
-        I.propsBlocks = SF3D_MAX_BLOCKS;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            I.propsBlocks = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;
-        if (const char* e = getenv("SF3D_PROPS_BLOCKS")) if (atoi(e) > 0) I.propsBlocks = (uint32_t)atoi(e);
-    }
-    const dim3 propsGrid(v.nb < I.propsBlocks ? v.nb : I.propsBlocks);
+    const dim3 propsGrid = resident((const void*)k_props<0, false>), propsHeatGrid = resident((const void*)k_props<0, true>);
+    const dim3 acceptGrid = v.ntStream ? resident((const void*)k_accept<true>) : resident((const void*)k_accept<false>);
     /* one approximation's worth of guarded kernels */
     auto enqueue_props = [&] {
             if (heatOn && multi) {      /* sharded heat always uses the fused exchange; halo conductivities are recomputed locally */
@@ -2332,7 +2343,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_halo_copy<0>, pgrid, block, 0, st, v);
                 hipLaunchKernelGGL(k_heat_halo_water, pgrid, block, 0, st, v);
             }
-            else if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), grid, block, 0, st, v); });
+            else if (heatOn) timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, true>), propsHeatGrid, block, 0, st, v); });
             else if (multi && fusedMulti) { timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<2, false>), grid, block, 0, st, v); }); hipLaunchKernelGGL(k_halo_copy<0>, pgrid, block, 0, st, v); }
             else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), propsGrid, block, 0, st, v); });
             if (multi && !fusedMulti) {
@@ -2374,7 +2385,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
             }
             if (overlap) hipLaunchKernelGGL(k_accept_boundary, grid, block, 0, st, v);
-            else timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, grid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, grid, block, 0, st, v); });
+            else timed(KID_ACCEPT, [&] { if (v.ntStream) hipLaunchKernelGGL(k_accept<true>, acceptGrid, block, 0, st, v); else hipLaunchKernelGGL(k_accept<false>, acceptGrid, block, 0, st, v); });
         }
     };
 
@@ -2472,7 +2483,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         /* heat part of computeStep (soilFluxes3D.cpp:1802-1818): every kernel is guarded by Ctrl::hStage; one batch =
          * boundary, node properties, rows, a run of sweeps, balance, flux bookkeeping; polled once per batch */
         hipLaunchKernelGGL(k_heat_begin, one, one, 0, st, v.ctrl, maxTimeStep, m.water ? 1 : 0);
-        hipLaunchKernelGGL(k_heat_save_water, grid, block, 0, st, v);
+        const dim3 gSaveWater = resident((const void*)k_heat_save_water), gBoundary = resident((const void*)k_heat_boundary),
+                   gHProps = resident((const void*)k_heat_props), gHAsm = resident((const void*)k_heat_assemble),
+                   gHPost = resident((const void*)k_heat_post), gHSave = resident((const void*)k_heat_save);
+        hipLaunchKernelGGL(k_heat_save_water, gSaveWater, block, 0, st, v);
         int hguard = 0;
         uint32_t lookH = I.lastHeatSteps < 1 ? 1 : (I.lastHeatSteps > 8 ? 8 : I.lastHeatSteps);
         if (v.heat.gs) lookH = 1;              /* one launch per dependency level: keep the queue short */
@@ -2481,9 +2495,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
          * from an instantiated hipGraph per shape like the water batches */
         auto enqueue_heat = [&](uint32_t steps, uint32_t chunk) {
             for (uint32_t bq = 0; bq < steps; ++bq) {
-                hipLaunchKernelGGL(k_heat_boundary, grid, block, 0, st, v);
-                hipLaunchKernelGGL(k_heat_props, grid, block, 0, st, v);
-                hipLaunchKernelGGL(k_heat_assemble, grid, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_boundary, gBoundary, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_props, gHProps, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_assemble, gHAsm, block, 0, st, v);
                 if (v.heat.gs) {
                     for (uint32_t k = 0; k < chunk; ++k) {
                         hipLaunchKernelGGL(k_heat_gs_begin, grid, block, 0, st, v);
@@ -2495,8 +2509,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                     }
                 } else
                 for (uint32_t k = 0; k < chunk; ++k) hipLaunchKernelGGL(k_heat_sweep, grid, block, 0, st, v);
-                hipLaunchKernelGGL(k_heat_post, grid, block, 0, st, v);
-                if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, grid, block, 0, st, v);
+                hipLaunchKernelGGL(k_heat_post, gHPost, block, 0, st, v);
+                if (v.heat.save != 0) hipLaunchKernelGGL(k_heat_save, gHSave, block, 0, st, v);
             }
         };
         auto launch_heat = [&](uint32_t steps, uint32_t chunk) -> hipError_t {
