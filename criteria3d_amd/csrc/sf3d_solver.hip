@@ -951,25 +951,62 @@ __device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i
     }
 }
 
+/* scales the row (preconditioningMatrix, cpusolver.cpp:284-305), stores it, and leaves the scaled coefficients in k
+ * and the right-hand side in the return value for the fused first sweep */
 template <bool NT>
-__device__ __forceinline__ void store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&k)[SF3D_SLOTS],
-                                          double sum, double Hoi, double dt, double invariantFlux)
+__device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, double (&k)[SF3D_SLOTS],
+                                            double sum, double Hoi, double dt, double invariantFlux)
 {
     const double Ci = (i < v.ns) ? v.size[i] : v.C[i];            /* surface capacity = area, cpusolver.cpp:151 */
     const double cdt = Ci / dt;
     const double inv = 1.0 / (cdt + sum);
     #pragma unroll
-    for (int p = 0; p < SF3D_SLOTS / 2; ++p)
-        if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) {
-            store_coeff<NT>(&v.A2[(size_t)p * v.N + i], (k[2 * p] * -1.) * inv, (k[2 * p + 1] * -1.) * inv);
-        }
-    v.b[i] = ((cdt * Hoi) + v.flow[i] + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
+    for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
+        k[2 * p] = (k[2 * p] * -1.) * inv; k[2 * p + 1] = (k[2 * p + 1] * -1.) * inv;
+        if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) store_coeff<NT>(&v.A2[(size_t)p * v.N + i], k[2 * p], k[2 * p + 1]);
+    }
+    const double bi = ((cdt * Hoi) + v.flow[i] + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
+    v.b[i] = bi;
+    return bi;
+}
+
+/* The first Jacobi sweep of an approximation (JacobiWaterCPU, water.cpp:565-601) for the row that was just assembled:
+ * its coefficients and right-hand side are still in registers, so the sweep's 112 B/node of matrix, b, z and x reads are
+ * saved - the same statements in the same order as k_sweep, hence the same bits.  Returns the row's norm term. */
+template <bool NT>
+__device__ __forceinline__ double first_sweep_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&a)[SF3D_SLOTS],
+                                                  double bi, const double* __restrict__ xin, double* __restrict__ xout)
+{
+    uint32_t j[SF3D_SLOTS];
+    double xj[SF3D_SLOTS];
+    __builtin_amdgcn_sched_barrier(0);        /* the gathers below must not be hoisted into the assembly (registers) */
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) {
+        if (cd.kind[s] == CK_MIXED) j[s] = load_stream<NT>(&v.lto[(size_t)s * v.N + i]);
+        else j[s] = i + cd.delta[s];
+    }
+    const double zi = v.z[i], xi = xin[i];
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
+    double xn = bi;
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    #pragma unroll
+    for (int o = 0; o < SF3D_SLOTS; ++o) {
+        const uint32_t s = order[o];
+        if (a[s] != 0.) xn -= a[s] * xj[s];
+    }
+    if (i < v.ns) xn = dmax(xn, zi);
+    double d = fabs(xn - xi);
+    const double psi = fabs(xn - zi);
+    if (psi > 1.) d *= (1. / psi);
+    xout[i] = xn;
+    return d;
 }
 
 /* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
  * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
-template <bool NT, bool HEAT>
-__device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk)
+template <bool NT, bool HEAT, bool SWEEP0>
+__device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk, double* __restrict__ xout, double& nrm)
 {
     const Ctrl* c = v.ctrl;
     const double* __restrict__ Xc = v.X[c->cur];
@@ -1002,7 +1039,8 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
             k[s] = ks;
             sum += ks;
         }
-        store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
     }
     return block_max(courant);
 }
@@ -1019,8 +1057,8 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
-template <bool NT, bool HEAT>
-__device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk)
+template <bool NT, bool HEAT, bool SWEEP0>
+__device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk, double* __restrict__ xout, double& nrm)
 {
     const Ctrl* c = v.ctrl;
     const double* __restrict__ Xc = v.X[c->cur];
@@ -1078,33 +1116,46 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
 #endif
             }
         }
-        store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
     }
 }
 
 /* one launch: blocks [0, nbSurf) assemble the surface rows (and reduce the Courant maximum),
  * blocks [nbSurf, nbSurf + nbSoil) the soil rows.  FUSED: the block that arrives last takes the
  * Courant decision (checkCourant) instead of a separate one-block kernel. */
-template <bool FUSED, bool NT, bool HEAT>
+/* SWEEP0 (one GPU, fused decisions, SF3D_FUSE_FIRST_SWEEP=1): every row is also swept once while it is in registers
+ * (first_sweep_row) and the last block, after a passed Courant check, takes the convergence decision of that first iteration -
+ * one k_sweep launch less per approximation.  After a failed Courant check the swept values sit in a free buffer and are
+ * never looked at.  Same results, but off by default: at 4 waves/SIMD the eleven extra gathers cost k_assemble 186 us, more
+ * than the 126 us sweep they replace. */
+template <bool FUSED, bool NT, bool HEAT, bool SWEEP0 = false>
 __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
     fm_init();
-    double bm = 0.;
-    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT>(v, blockIdx.x, v.nbSurf);
-    else assemble_soil_rows<NT, HEAT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
+    const int nxt = free_buffer(v.ctrl);                  /* where k_sweep would write its first iterate */
+    double* __restrict__ xout = v.X[nxt];
+    double bm = 0., nrm = 0.;
+    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, v.nbSurf, xout, nrm);
+    else assemble_soil_rows<NT, HEAT, SWEEP0>(v, blockIdx.x - v.nbSurf, v.nbSoil, xout, nrm);
     if (!FUSED) {
         if (threadIdx.x == 0 && blockIdx.x < v.nbSurf) v.part0[blockIdx.x] = bm;
         return;
     }
+    const double bs = SWEEP0 ? block_sum(nrm) : 0.;
     __syncthreads();
-    if (!arrive_last(v, bm, 0., false)) return;
+    if (!arrive_last(v, bm, bs, SWEEP0)) return;
     double m = 0.;                                        /* soil blocks published 0: the maximum is unchanged */
     for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK)
         m = dmax(m, __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     double vals[3] = {block_max(m), 0., 0.};
+    const double norm = SWEEP0 ? sum_published(v.part1, gridDim.x) : 0.;
     if (!dist_allgather(v, v.ctrl, vals, 1)) return;
-    if (threadIdx.x == 0) courant_decision(v.ctrl, vals[0]);
+    if (threadIdx.x == 0) {
+        courant_decision(v.ctrl, vals[0]);
+        if (SWEEP0 && v.ctrl->stage == ST_SWEEP) sweep_decision(v.ctrl, nxt, norm / v.N);
+    }
 }
 
 /* JacobiWaterCPU, water.cpp:565-601.
@@ -1517,6 +1568,7 @@ struct DeviceSolver::Impl {
     /* timing */
     int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
+    int fuseFirstSweep = -1;              /* SF3D_FUSE_FIRST_SWEEP=1: k_assemble also does the first Jacobi iteration (measured slower) */
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
@@ -2278,6 +2330,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool heatOn = v.heat.on != 0;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
     if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
+    if (I.fuseFirstSweep < 0) { const char* e = getenv("SF3D_FUSE_FIRST_SWEEP"); I.fuseFirstSweep = (e && e[0] == '1') ? 1 : 0; }   /* measured slower: off */
+    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn;      /* k_assemble also does the first Jacobi iteration */
     /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
      * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
      * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
@@ -2356,13 +2410,14 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
+            else if (fuse0) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
                 timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
-        uint32_t chunk = I.lastSweeps + 2;
+        uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
         for (uint32_t k = 0; k < chunk; ++k) {
@@ -2397,7 +2452,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps) -> hipError_t {
         if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps); return hipSuccess; }
-        uint32_t chunk = I.lastSweeps + 2;
+        uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
         const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u);
@@ -2442,6 +2497,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             uint64_t ran[KID_COUNT];
             ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
             ran[KID_SWEEP] = c.counters[3] - before[3];
+            if (fuse0) ran[KID_SWEEP] -= (c.counters[2] - before[2]) - (c.counters[4] - before[4]);   /* first iterations: inside k_assemble */
             ran[KID_POST] = c.counters[7] - before[7];
             ran[KID_RESTORE] = c.counters[6] - before[6];
             ran[KID_ACCEPT] = c.counters[1] - before[1];
