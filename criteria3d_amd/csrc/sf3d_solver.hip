@@ -955,9 +955,8 @@ __device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i
  * and the right-hand side in the return value for the fused first sweep */
 template <bool NT>
 __device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, double (&k)[SF3D_SLOTS],
-                                            double sum, double Hoi, double dt, double invariantFlux)
+                                            double sum, double Hoi, double dt, double invariantFlux, double Ci, double flowi)
 {
-    const double Ci = (i < v.ns) ? v.size[i] : v.C[i];            /* surface capacity = area, cpusolver.cpp:151 */
     const double cdt = Ci / dt;
     const double inv = 1.0 / (cdt + sum);
     #pragma unroll
@@ -965,7 +964,7 @@ __device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& c
         k[2 * p] = (k[2 * p] * -1.) * inv; k[2 * p + 1] = (k[2 * p + 1] * -1.) * inv;
         if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) store_coeff<NT>(&v.A2[(size_t)p * v.N + i], k[2 * p], k[2 * p + 1]);
     }
-    const double bi = ((cdt * Hoi) + v.flow[i] + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
+    const double bi = ((cdt * Hoi) + flowi + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
     v.b[i] = bi;
     return bi;
 }
@@ -1022,6 +1021,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];
         const double Hi = Xc[i], Hoi = Xh[i], zi = v.z[i];
+        const double Ci = (i < v.ns) ? v.size[i] : v.C[i], flowi = v.flow[i];     /* surface capacity = area, cpusolver.cpp:151 */
         double k[SF3D_SLOTS];
         double sum = 0., invFlux = 0.;
         #pragma unroll
@@ -1039,7 +1039,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
             k[s] = ks;
             sum += ks;
         }
-        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
         if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
     }
     return block_max(courant);
@@ -1074,6 +1074,7 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
         const double Hoi = Xh[i], Ki = v.K[i];
+        const double Ci = v.C[i], flowi = v.flow[i];       /* for the row's diagonal and right-hand side: requested with the first loads, not after the last logarithm */
         double k[SF3D_SLOTS];
         double sum = 0., invFlux = 0.;
         #pragma unroll
@@ -1116,7 +1117,7 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
 #endif
             }
         }
-        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux);
+        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
         if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
     }
 }
