@@ -1057,6 +1057,9 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
+#ifndef SF3D_ASM_GROUPS
+#define SF3D_ASM_GROUPS 2      /* 2 groups of 5 slots (5 groups of 2, 1 of 10: tuning experiments) */
+#endif
 template <bool NT, bool HEAT, bool SWEEP0>
 __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk, double* __restrict__ xout, double& nrm)
 {
@@ -1078,12 +1081,13 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
         double k[SF3D_SLOTS];
         double sum = 0., invFlux = 0.;
         #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            uint32_t j[5]; uint8_t kd[5];
-            double area[5], dist[5], kj[5];
+        for (int g = 0; g < SF3D_ASM_GROUPS; ++g) {
+            constexpr int GS = SF3D_SLOTS / SF3D_ASM_GROUPS;          /* slots per group */
+            uint32_t j[GS]; uint8_t kd[GS];
+            double area[GS], dist[GS], kj[GS];
             #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const uint32_t s = order[g * 5 + t];
+            for (int t = 0; t < GS; ++t) {
+                const uint32_t s = order[g * GS + t];
                 kd[t] = LK_NONE; j[t] = i; area[t] = 0.; dist[t] = 1.;
                 if (cd.kind[s] != CK_NONE) {
                     const size_t e = (size_t)s * v.N + i;
@@ -1094,10 +1098,10 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 }
             }
             #pragma unroll
-            for (int t = 0; t < 5; ++t) kj[t] = v.K[j[t]];
+            for (int t = 0; t < GS; ++t) kj[t] = v.K[j[t]];
             #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                const uint32_t s = order[g * 5 + t];
+            for (int t = 0; t < GS; ++t) {
+                const uint32_t s = order[g * GS + t];
                 double ks = 0.;
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
