@@ -83,9 +83,13 @@ def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     outs = []
-    for fused, graphs, overlap in (("1", "1", "1"), ("0", "0", "1"), ("1", "1", "0")):
-        out = tmp_path / f"{case}_{fused}{graphs}{overlap}.npz"
-        env = dict(os.environ, SF3D_FUSED_DECIDE=fused, SF3D_GRAPHS=graphs, SF3D_OVERLAP_ACCEPT=overlap)
+    # + the two grid / fusion switches: the common 2 048-block grid for every kernel, and the first Jacobi iteration inside
+    # k_assemble (its norm is summed over another block layout: equal decisions, hence equal fields)
+    for fused, graphs, overlap, resident, first in (("1", "1", "1", "1", "0"), ("0", "0", "1", "1", "0"), ("1", "1", "0", "1", "0"),
+                                                    ("1", "1", "1", "0", "0"), ("1", "1", "1", "1", "1")):
+        out = tmp_path / f"{case}_{fused}{graphs}{overlap}{resident}{first}.npz"
+        env = dict(os.environ, SF3D_FUSED_DECIDE=fused, SF3D_GRAPHS=graphs, SF3D_OVERLAP_ACCEPT=overlap,
+                   SF3D_RESIDENT_GRIDS=resident, SF3D_FUSE_FIRST_SWEEP=first)
         p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
                            capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, p.stdout + p.stderr
