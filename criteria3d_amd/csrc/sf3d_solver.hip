@@ -111,6 +111,14 @@ __device__ __forceinline__ double flog(double x)
     return log(x);
 #endif
 }
+__device__ __forceinline__ double fexp(double x)
+{
+#if SF3D_FAST_POW
+    return sf3d_fexp(x);
+#else
+    return exp(x);
+#endif
+}
 extern "C" __device__ double __ocml_powr_f64(double, double);
 __device__ __forceinline__ double ppow(double x, double y)
 {
@@ -164,15 +172,8 @@ __device__ __forceinline__ double reduce_partials_max(const double* p, uint32_t 
 }
 
 /* ---- Math::computeMean (otherFunctions.cpp:7-36) ---- */
-/* mean_of: library log (kernels that evaluate a handful of means); mean_of_fast: the table-driven log - only inside kernels
- * that have called flog_init() (the two assembly kernels, where the logarithm is ~70 % of the arithmetic) */
+/* the logarithm is the table-driven one: every kernel that evaluates a mean has called fm_init() */
 __device__ __forceinline__ double mean_of(double v1, double v2, uint32_t type)
-{
-    if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
-    if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
-    return (v1 == v2) ? v1 : (v1 - v2) / log(v1 / v2);
-}
-__device__ __forceinline__ double mean_of_fast(double v1, double v2, uint32_t type)
 {
     if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
     if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
@@ -859,9 +860,6 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_halo_copy(DevView v)
 }
 
 /* infiltration, water.cpp:490-539: one end is a surface node, the other a soil node */
-/* FAST: table-driven log in the mean (soil rows); the surface rows keep the library call - their ten-way link dispatch is
- * already at the register limit and evaluates one mean per node */
-template <bool FAST>
 __device__ __forceinline__ double infiltration_conductance(const DevView& v, const Ctrl* c, uint32_t i, uint32_t j, size_t e,
                                                            const double* __restrict__ Xc, const double* __restrict__ Xh,
                                                            double Hi, double Hoi, double zi)
@@ -891,7 +889,7 @@ __device__ __forceinline__ double infiltration_conductance(const DevView& v, con
     if (maxInfRate < 2.78e-11) return 0.;
     const double dH = dmax(surfH - soilH, 1e-12);
     const double maxK = maxInfRate * (dist / dH);
-    const double meanK = FAST ? mean_of_fast(s.Ksat, v.K[so], c->meanType) : mean_of(s.Ksat, v.K[so], c->meanType);
+    const double meanK = mean_of(s.Ksat, v.K[so], c->meanType);
     return (dmin(factor * meanK, maxK) * area) / dist;
 }
 
@@ -932,7 +930,7 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
         courant = dmax(courant, vel * dt / dist);
         return Kij;
     }
-    return infiltration_conductance<false>(v, c, i, j, e, Xc, Xh, Hi, Hoi, zi);
+    return infiltration_conductance(v, c, i, j, e, Xc, Xh, Hi, Hoi, zi);
 }
 
 /* computeLinearSystemElement (cpusolver.cpp:348-389, order Up, laterals, Down) +
@@ -943,10 +941,10 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
 __device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i, uint32_t j, double area, double dist3, double& inv)
 {
     const double Ti = hv.wTm[i], Tj = hv.wTm[j];
-    const double avgL = mean_of_fast(hv.wThLiq[i], hv.wThLiq[j], SF3D_MEAN_LOGARITHMIC);
+    const double avgL = mean_of(hv.wThLiq[i], hv.wThLiq[j], SF3D_MEAN_LOGARITHMIC);
     inv += (avgL * (Tj - Ti) / dist3) * area;
     if (hv.vapor) {
-        const double avgV = mean_of_fast(hv.wThVap[i], hv.wThVap[j], SF3D_MEAN_LOGARITHMIC);
+        const double avgV = mean_of(hv.wThVap[i], hv.wThVap[j], SF3D_MEAN_LOGARITHMIC);
         inv += ((avgV * (Tj - Ti) / dist3) * area) / H_RHOW;
     }
 }
@@ -1105,11 +1103,11 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 double ks = 0.;
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
-                    ks = (mean_of_fast(ki, kn, meanType) * area[t]) / dist[t];
+                    ks = (mean_of(ki, kn, meanType) * area[t]) / dist[t];
                 } else if (kd[t] == LK_SOIL_VERT) {
-                    ks = (mean_of_fast(Ki, kj[t], meanType) * area[t]) / dist[t];
+                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dist[t];
                 } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
-                    ks = infiltration_conductance<true>(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
+                    ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
                 }                                                            /* a soil row has no runoff link */
                 if (HEAT && (kd[t] == LK_SOIL_LAT || kd[t] == LK_SOIL_VERT))
                     add_thermal_fluxes(v.heat, i, j[t], area[t], v.heat.hdist[(size_t)s * v.N + i], invFlux);
@@ -2264,6 +2262,12 @@ __global__ void k_device_log(const double* x, double* y, uint32_t n)
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = flog(x[i]);
 }
+__global__ void k_device_exp(const double* x, double* y, uint32_t n)
+{
+    fm_init();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fexp(x[i]);
+}
 __global__ void k_device_pow(const double* x, const double* e, double* y, uint32_t n)
 {
     fm_init();
@@ -2271,37 +2275,39 @@ __global__ void k_device_pow(const double* x, const double* e, double* y, uint32
     if (i < n) y[i] = ppow(x[i], e[i]);
 }
 
-/* test hook: the link kernels' logarithm on host values */
-sf3d_error_t DeviceSolver::device_log(uint32_t n, const double* x, double* out)
+/* test hooks: the kernels' logarithm / pow on host values */
+namespace {
+struct DevBuf {                      /* scratch device array, released on every exit path */
+    double* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}
+sf3d_error_t DeviceSolver::device_log(uint32_t n, const double* x, double* out, bool exponential)
 {
     if (n == 0) return SF3D_OK;
-    double *dx = nullptr, *dy = nullptr;
-    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
-    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_device_log, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, n);
+    DevBuf dx, dy;
+    HIP_TRY(hipMalloc(&dx.p, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy.p, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (exponential) hipLaunchKernelGGL(k_device_exp, dim3((n + 255) / 256), dim3(256), 0, 0, dx.p, dy.p, n);
+    else hipLaunchKernelGGL(k_device_log, dim3((n + 255) / 256), dim3(256), 0, 0, dx.p, dy.p, n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dy, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dx));
-    HIP_TRY(hipFree(dy));
+    HIP_TRY(hipMemcpy(out, dy.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SF3D_OK;
 }
 
 sf3d_error_t DeviceSolver::device_pow(uint32_t n, const double* x, const double* y, double* out)
 {
     if (n == 0) return SF3D_OK;
-    double *dx = nullptr, *dy = nullptr, *dz = nullptr;
-    HIP_TRY(hipMalloc(&dx, (size_t)n * 8));
-    HIP_TRY(hipMalloc(&dy, (size_t)n * 8));
-    HIP_TRY(hipMalloc(&dz, (size_t)n * 8));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dy, y, (size_t)n * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_device_pow, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dy, dz, n);
+    DevBuf dx, dy, dz;
+    HIP_TRY(hipMalloc(&dx.p, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dy.p, (size_t)n * 8));
+    HIP_TRY(hipMalloc(&dz.p, (size_t)n * 8));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy.p, y, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_device_pow, dim3((n + 255) / 256), dim3(256), 0, 0, dx.p, dy.p, dz.p, n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, dz, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(dx));
-    HIP_TRY(hipFree(dy));
-    HIP_TRY(hipFree(dz));
+    HIP_TRY(hipMemcpy(out, dz.p, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SF3D_OK;
 }
 

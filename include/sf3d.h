@@ -352,6 +352,8 @@ sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint
 /* Test hooks: the logarithm the link kernels use for the logarithmic mean (a table-driven routine) evaluated on
  * the device for `count` host values; tests compare it bit for bit with the host build of the same source. */
 sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out);
+/* the same for the exp of the heat kernels */
+sf3d_error_t sf3d_device_exp(uint32_t count, const double* x, double* out);
 /* the same for the pow of the soil-property kernels: out[k] = x[k]^y[k], x >= 0 */
 sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out);
 

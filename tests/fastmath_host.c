@@ -9,3 +9,5 @@ void fm_log(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++
 void fm_log_libm(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = log(x[i]); }
 void fm_pow(const double* x, const double* y, double* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sf3d_fpow(x[i], y[i]); }
 void fm_pow_libm(const double* x, const double* y, double* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = pow(x[i], y[i]); }
+void fm_exp(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = sf3d_fexp(x[i]); }
+void fm_exp_libm(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = exp(x[i]); }

@@ -136,3 +136,27 @@ def test_pow_special_values_as_the_library(fm):
     assert np.all(np.abs(a[sub] - b[sub]) <= 5e-324)
     # negative bases are outside the routine's contract (the soil functions never produce one): nan like powr
     assert np.all(np.isnan(fm("fm_pow", np.array([-1.0, -0.5]), np.array([2.0, 0.5]))))
+
+
+def exp_samples(seed=9, n=300_000):
+    rng = np.random.default_rng(seed)
+    return {"heat arguments": rng.uniform(-30, 30, n), "small": rng.uniform(-1e-3, 1e-3, n), "whole range": rng.uniform(-745, 709.7, n),
+            "special": np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 709.78, 709.79, 710.0, -745.0, -745.2, -708.0, -720.0, 1e-320, 1.0, -1.0])}
+
+
+def test_exp_agrees_with_libm_and_mpmath(fm):
+    import mpmath as mp
+    mp.mp.prec = 200
+    for name, x in exp_samples().items():
+        a, b = fm("fm_exp", x), fm("fm_exp_libm", x)
+        normal = np.isfinite(b) & (b >= 2.2250738585072014e-308)
+        assert np.array_equal(a[~normal & ~(np.isfinite(b) & (b > 0))], b[~normal & ~(np.isfinite(b) & (b > 0))], equal_nan=True), name
+        d = np.abs(a.view(np.int64) - b.view(np.int64))[np.isfinite(b) & (b > 0)]
+        assert d.size == 0 or d.max() <= 1, name
+        assert d.size == 0 or (d > 0).mean() < 0.003 or name == "special", name      # measured 0.08 %
+    worst = 0.0
+    x = exp_samples(seed=10, n=8000)["heat arguments"]
+    for xv, yv in zip(x, fm("fm_exp", x)):
+        t = mp.exp(mp.mpf(float(xv)))
+        worst = max(worst, float(abs(mp.mpf(float(yv)) - t) / mp.mpf(float(np.spacing(float(t))))))
+    assert worst < 0.6, worst                       # measured 0.503

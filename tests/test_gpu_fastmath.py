@@ -7,7 +7,7 @@ from criteria3d_amd import capi
 
 import sys, os
 sys.path.insert(0, os.path.dirname(__file__))
-from test_fastmath import fm, pow_samples, samples  # noqa: F401  (fixture)
+from test_fastmath import exp_samples, fm, pow_samples, samples  # noqa: F401  (fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -42,3 +42,11 @@ def test_device_pow_special_values(product, fm):  # noqa: F811
     out = np.empty_like(x)
     product.check(product.lib.sf3d_device_pow(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd), out.ctypes.data_as(capi.pd)), "device_pow")
     assert np.array_equal(out, fm("fm_pow", x, y), equal_nan=True)
+
+
+def test_device_exp_equals_host_build(product, fm):  # noqa: F811
+    for name, x in exp_samples(seed=11, n=1_000_000).items():
+        x = np.ascontiguousarray(x)
+        y = np.empty_like(x)
+        product.check(product.lib.sf3d_device_exp(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd)), "device_exp")
+        assert np.array_equal(y.view(np.int64), fm("fm_exp", x).view(np.int64)), name
