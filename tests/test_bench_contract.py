@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_has_every_contract_field():
-    files = sorted(glob.glob(str(ROOT / "profiles" / "r01_*_bench.json")))
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r01_?_bench.json")))
     assert files, "no committed bench line under profiles/"
     line = json.load(open(files[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
