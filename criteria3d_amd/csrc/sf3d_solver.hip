@@ -1114,8 +1114,10 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 k[s] = ks;
                 sum += ks;
 #if SF3D_ASM_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0);      /* one link's divide -> log -> divide chain at a time: the scheduler would
-                                                         * otherwise interleave the five of a group and run out of registers */
+                if ((t + 1) % SF3D_ASM_SCHED_BARRIER == 0)
+                    __builtin_amdgcn_sched_barrier(0);  /* one link's divide -> log -> divide chain at a time (every N-th link with
+                                                         * -DSF3D_ASM_SCHED_BARRIER=N): the scheduler would otherwise interleave
+                                                         * the five of a group and run out of registers (371 us instead of 304) */
 #endif
             }
         }
