@@ -46,6 +46,62 @@ __global__ void __launch_bounds__(256) k_single(Grid g, const double* __restrict
     }
 }
 
+// k_single + what the product's k_sweep does on top: the node's own x and the scaled norm, a block reduction, a last-block
+// hand-off (two-level counter) with a fixed-order sum of the partials; LIST: chunk list + per-chunk descriptor indirection
+struct Desc { int delta[SLOTS]; int pad[6]; };
+template <bool LIST>
+__global__ void __launch_bounds__(256, 8) k_single_full(Grid g, const double* __restrict__ xin, double* __restrict__ xout,
+                                                      const uint32_t* __restrict__ list, const Desc* __restrict__ desc,
+                                                      double* part, unsigned* arrive, double* result)
+{
+    const size_t chunks = g.N / 64;
+    const uint32_t lane = threadIdx.x & 63u;
+    double nrm = 0.;
+    for (size_t li = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); li < chunks; li += (size_t)gridDim.x * 4) {
+        const size_t q = LIST ? __builtin_amdgcn_readfirstlane(list[li]) : li;
+        const size_t i = q * 64 + lane;
+        double a[SLOTS], xj[SLOTS];
+        #pragma unroll
+        for (int p = 0; p < 5; ++p) { const d2 t = ntload(&g.A2[(size_t)p * g.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+        const double bi = g.b[i], zi = g.z[i], xi = xin[i];
+        if (LIST) {
+            const Desc d = desc[q];
+            #pragma unroll
+            for (int s = 0; s < SLOTS; ++s) xj[s] = xin[(a[s] != 0.) ? i + d.delta[s] : i];
+        } else {
+            #pragma unroll
+            for (int s = 0; s < SLOTS; ++s) xj[s] = xin[(a[s] != 0.) ? i + cDelta[s] : i];
+        }
+        double xn = bi;
+        #pragma unroll
+        for (int o = 0; o < SLOTS; ++o) { const int s = ORDER[o]; if (a[s] != 0.) xn -= a[s] * xj[s]; }
+        if (i < (size_t)g.NX * g.NY) xn = (xn < zi) ? zi : xn;
+        double d = fabs(xn - xi); const double psi = fabs(xn - zi); if (psi > 1.) d *= (1. / psi);
+        nrm += d;
+        xout[i] = xn;
+    }
+    __shared__ double sm[4]; __shared__ int sLast;
+    for (int off = 32; off > 0; off >>= 1) nrm += __shfl_down(nrm, off, 64);
+    if (lane == 0) sm[threadIdx.x >> 6] = nrm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // like the product's arrive_last: an agent-scope relaxed store + wait, no __threadfence() (on this part an agent-scope
+        // release writes the XCD's L2 back: with it every block pays for the sweep's dirty lines and the kernel takes twice as long)
+        __hip_atomic_store(&part[blockIdx.x], (sm[0] + sm[1]) + (sm[2] + sm[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sLast = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (sLast) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sLast) return;
+    double s2 = 0.;
+    for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) s2 += __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) s2 += __shfl_down(s2, off, 64);
+    if (lane == 0) sm[threadIdx.x >> 6] = s2;
+    __syncthreads();
+    if (threadIdx.x == 0) *result = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / g.N;
+}
+
 // two sweeps per pass.  W waves per block (W rows of the patch), inner rows 1..W-2, inner lanes 1..62.
 template <int W, int OCC>
 __global__ void __launch_bounds__(W * 64, OCC) k_pair(Grid g, const double* __restrict__ xin, double* __restrict__ xout, int patchCols)
@@ -204,6 +260,16 @@ int main(int argc, char** argv)
 
     const float tSingle = timeit([&] { k_single<<<2048, 256>>>(g, dx0, dx1); k_single<<<2048, 256>>>(g, dx1, dx2); }, 20);
     printf("%d x %d x %d: two single sweeps: %.1f us (%.1f us each)\n", NX, NY, NZ, tSingle, tSingle / 2);
+    {
+        std::vector<uint32_t> hl(N / 64); for (size_t q = 0; q < N / 64; ++q) hl[q] = (uint32_t)q;
+        std::vector<Desc> hd(N / 64); for (auto& d : hd) for (int s = 0; s < SLOTS; ++s) d.delta[s] = delta[s];
+        uint32_t* dl; Desc* dd; double *dpart, *dres; unsigned* darr;
+        CHECK(hipMalloc(&dl, hl.size() * 4)); CHECK(hipMalloc(&dd, hd.size() * sizeof(Desc))); CHECK(hipMalloc(&dpart, 4096 * 8)); CHECK(hipMalloc(&dres, 8)); CHECK(hipMalloc(&darr, 4));
+        CHECK(hipMemcpy(dl, hl.data(), hl.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dd, hd.data(), hd.size() * sizeof(Desc), hipMemcpyHostToDevice)); CHECK(hipMemset(darr, 0, 4));
+        const float tA = timeit([&] { k_single_full<false><<<2048, 256>>>(g, dx0, dx1, dl, dd, dpart, darr, dres); k_single_full<false><<<2048, 256>>>(g, dx1, dx2, dl, dd, dpart, darr, dres); }, 20);
+        const float tB = timeit([&] { k_single_full<true><<<2048, 256>>>(g, dx0, dx1, dl, dd, dpart, darr, dres); k_single_full<true><<<2048, 256>>>(g, dx1, dx2, dl, dd, dpart, darr, dres); }, 20);
+        printf("  + own x, norm, block reduction, last-block sum: %.1f us each;  + chunk list and descriptor: %.1f us each\n", tA / 2, tB / 2);
+    }
     std::vector<double> ref(N), got(N);
     CHECK(hipMemcpy(ref.data(), dx2, N * 8, hipMemcpyDeviceToHost));
 
