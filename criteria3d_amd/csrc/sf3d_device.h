@@ -65,7 +65,9 @@ struct ChunkDesc {
     uint8_t rowType;                    /* 0 all surface nodes, 1 all soil nodes, 2 straddles nrSurfaceNodes */
     uint8_t pad0;                       /* multi GPU: 1 = some node of the chunk has a neighbour owned by another rank */
     uint16_t areaUniform;               /* bit s: every link of slot s in the chunk has interface area area[s] */
-    uint8_t pad1[10];
+    uint16_t sweepUniform;              /* bit s: kind[s] is CK_MIXED only because some nodes lack the link - every existing one has
+                                         * j = i + delta[s] (row ends of a regular grid): the sweep needs no lto there */
+    uint8_t pad1[8];
     double area[SF3D_SLOTS];            /* (cell size and layer thickness make it constant over regular grids) */
 };
 

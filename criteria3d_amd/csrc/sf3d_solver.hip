@@ -1193,8 +1193,11 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
             const ChunkDesc cd = v.cdesc[q];                                     /* wave-uniform: scalar load */
             #pragma unroll
             for (int s = 0; s < SF3D_SLOTS; ++s) {
-                if (cd.kind[s] == CK_MIXED) j[s] = load_stream<NT>(&v.lto[(size_t)s * v.N + i]);   /* 0 for a missing link: in range */
-                else j[s] = i + cd.delta[s];                                     /* offset 0 when the slot is empty */
+                if (cd.kind[s] != CK_MIXED) j[s] = i + cd.delta[s];              /* offset 0 when the slot is empty */
+                else if ((cd.sweepUniform >> s) & 1u) {                          /* row end: the nodes without the link have a zero coefficient */
+                    const int64_t jj = (int64_t)i + cd.delta[s];
+                    j[s] = (jj < 0 || jj >= (int64_t)v.N) ? i : (uint32_t)jj;
+                } else j[s] = load_stream<NT>(&v.lto[(size_t)s * v.N + i]);       /* 0 for a missing link: in range */
             }
             const double bi = v.b[i], zi = v.z[i], xi = xin[i];
             #pragma unroll
@@ -1738,19 +1741,21 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                 std::memset(&d, 0, sizeof(d));
                 d.rowType = (i1 <= ns) ? 0 : (i0 >= ns ? 1 : 2);
                 for (int s = 0; s < SF3D_SLOTS; ++s) {
-                    bool any = false, all = true, same = true;
+                    bool any = false, all = true, same = true, sameDelta = true;
                     uint8_t k0 = LK_NONE; int64_t d0 = 0;
                     for (uint32_t i = i0; i < i1; ++i) {
                         const size_t e = (size_t)s * N + i;
                         if (kind[e] == LK_NONE) { all = false; continue; }
                         const int64_t dd = (int64_t)to[e] - (int64_t)i;
                         if (!any) { any = true; k0 = kind[e]; d0 = dd; }
-                        else if (kind[e] != k0 || dd != d0) same = false;
+                        else { if (kind[e] != k0 || dd != d0) same = false; if (dd != d0) sameDelta = false; }
                     }
+                    const bool fits = d0 >= INT32_MIN && d0 <= INT32_MAX;
                     uint8_t ck = CK_NONE;
-                    if (any) ck = (all && same && d0 >= INT32_MIN && d0 <= INT32_MAX) ? k0 : (uint8_t)CK_MIXED;
+                    if (any) ck = (all && same && fits) ? k0 : (uint8_t)CK_MIXED;
                     d.kind[s] = ck;
                     d.delta[s] = (ck != CK_NONE && ck != CK_MIXED) ? (int32_t)d0 : 0;
+                    if (ck == CK_MIXED && sameDelta && fits) { d.delta[s] = (int32_t)d0; d.sweepUniform |= (uint16_t)(1u << s); }   /* only the sweep looks at this */
                     if (any) {                                   /* one interface area for the whole chunk? */
                         bool first = true, uni = true; double a0 = 0.;
                         for (uint32_t i = i0; i < i1 && uni; ++i) {
