@@ -102,6 +102,17 @@ __global__ void __launch_bounds__(256, 8) k_single_full(Grid g, const double* __
     if (threadIdx.x == 0) *result = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / g.N;
 }
 
+// an fp64-transcendental burst like k_props / k_assemble: does the sweep after it run slower (clocks, power)?
+__global__ void __launch_bounds__(256, 4) k_alu(const double* __restrict__ x, double* __restrict__ o, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        double v = x[i] * 1e-2, acc = 0;
+        #pragma unroll 1
+        for (int k = 0; k < 12; ++k) acc += pow(v + k * 1e-3, 1.3 + 0.01 * k);
+        o[i] = acc;
+    }
+}
+
 // two sweeps per pass.  W waves per block (W rows of the patch), inner rows 1..W-2, inner lanes 1..62.
 template <int W, int OCC>
 __global__ void __launch_bounds__(W * 64, OCC) k_pair(Grid g, const double* __restrict__ xin, double* __restrict__ xout, int patchCols)
@@ -269,6 +280,27 @@ int main(int argc, char** argv)
         const float tA = timeit([&] { k_single_full<false><<<2048, 256>>>(g, dx0, dx1, dl, dd, dpart, darr, dres); k_single_full<false><<<2048, 256>>>(g, dx1, dx2, dl, dd, dpart, darr, dres); }, 20);
         const float tB = timeit([&] { k_single_full<true><<<2048, 256>>>(g, dx0, dx1, dl, dd, dpart, darr, dres); k_single_full<true><<<2048, 256>>>(g, dx1, dx2, dl, dd, dpart, darr, dres); }, 20);
         printf("  + own x, norm, block reduction, last-block sum: %.1f us each;  + chunk list and descriptor: %.1f us each\n", tA / 2, tB / 2);
+    }
+    {   // sweeps timed one by one right after an ALU burst of ~0.4 ms, like the product's approximation
+        hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+        double tot = 0; int cnt = 0; float tb = 0;
+        for (int rep = 0; rep < 30; ++rep) {
+            hipEventRecord(a0, 0); k_alu<<<2048, 256>>>(dx0, dy, N); hipEventRecord(a1, 0); hipEventSynchronize(a1); hipEventElapsedTime(&tb, a0, a1);
+            k_alu<<<2048, 256>>>(dx0, dy, N);
+            for (int k = 0; k < 5; ++k) {
+                hipEventRecord(a0, 0); k_single<<<2048, 256>>>(g, (k & 1) ? dx1 : dx0, (k & 1) ? dx2 : dx1); hipEventRecord(a1, 0); hipEventSynchronize(a1);
+                float t; hipEventElapsedTime(&t, a0, a1); if (rep >= 5 && k >= 1) { tot += t; ++cnt; }
+            }
+        }
+        printf("  single sweeps 2..5 after an fp64 burst of %.0f us, timed one by one with events: %.1f us each\n", tb * 1e3, tot / cnt * 1e3);
+        tot = 0; cnt = 0;
+        for (int rep = 0; rep < 30; ++rep)
+            for (int k = 0; k < 5; ++k) {
+                hipEventRecord(a0, 0); k_single<<<2048, 256>>>(g, (k & 1) ? dx1 : dx0, (k & 1) ? dx2 : dx1); hipEventRecord(a1, 0); hipEventSynchronize(a1);
+                float t; hipEventElapsedTime(&t, a0, a1); if (rep >= 5) { tot += t; ++cnt; }
+            }
+        printf("  the same without the burst: %.1f us each\n", tot / cnt * 1e3);
+        k_single<<<2048, 256>>>(g, dx0, dx1); k_single<<<2048, 256>>>(g, dx1, dx2); hipDeviceSynchronize();
     }
     std::vector<double> ref(N), got(N);
     CHECK(hipMemcpy(ref.data(), dx2, N * 8, hipMemcpyDeviceToHost));
