@@ -238,6 +238,104 @@ __global__ void __launch_bounds__((W + 1) * 64) k_pair64(Grid g, const double* _
     }
 }
 
+// k_pair64 with everything the product would need around it: z for every node, the node's own x, x' stored for the inner cells
+// (so that a convergence hit after the first of the two iterations can use it), both scaled norms reduced per block and
+// summed by the last block (fence-free hand-off)
+template <int W>
+__global__ void __launch_bounds__((W + 1) * 64, 6) k_pair64_full(Grid g, const double* __restrict__ xin, double* __restrict__ xout1, double* __restrict__ xout,
+                                                             int patchCols, double* part, unsigned* arrive, double* result)
+{
+    __shared__ double ring[3][W][66];
+    __shared__ double sm[2][W + 1]; __shared__ int sLast;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pr = blockIdx.x / patchCols, pc = blockIdx.x % patchCols;
+    int r0 = pr * (W - 2) - 1, c0 = pc * 64;
+    if (r0 + W > g.NY + 1) r0 = g.NY + 1 - W;
+    if (c0 + 64 > g.NX) c0 = g.NX - 64;
+    const bool halo = wave == W;
+    const int prow = halo ? (lane >> 1) : wave;
+    const int r = r0 + prow;
+    const int c = halo ? ((lane & 1) ? c0 + 64 : c0 - 1) : c0 + lane;
+    const int slot = halo ? ((lane & 1) ? 65 : 0) : lane + 1;
+    const bool ok = r >= 0 && r < g.NY && c >= 0 && c < g.NX && prow < W;
+    const bool inner = !halo && ok && wave >= 1 && wave <= W - 2;
+    const size_t layer = (size_t)g.NX * g.NY;
+    const size_t i0 = ok ? (size_t)r * g.NX + c : 0;
+    double ap[SLOTS], bp = 0., zp = 0., n1 = 0., n2 = 0.;
+    #pragma unroll
+    for (int s = 0; s < SLOTS; ++s) ap[s] = 0.;
+    for (int t = 0; t <= g.NZ; ++t) {
+        double ac[SLOTS], bc = 0., zc = 0.;
+        #pragma unroll
+        for (int s = 0; s < SLOTS; ++s) ac[s] = 0.;
+        if (t < g.NZ && prow < W) {
+            double x1 = 0.;
+            if (ok) {
+                const size_t i = (size_t)t * layer + i0;
+                double xj[SLOTS];
+                #pragma unroll
+                for (int p = 0; p < 5; ++p) { const d2 v = ntload(&g.A2[(size_t)p * g.N + i]); ac[2 * p] = v.x; ac[2 * p + 1] = v.y; }
+                bc = g.b[i]; zc = g.z[i];
+                const double xi = xin[i];
+                #pragma unroll
+                for (int s = 0; s < SLOTS; ++s) xj[s] = (ac[s] != 0.) ? xin[i + cDelta[s]] : 0.;
+                x1 = bc;
+                #pragma unroll
+                for (int o = 0; o < SLOTS; ++o) { const int s = ORDER[o]; if (ac[s] != 0.) x1 -= ac[s] * xj[s]; }
+                if (t == 0) x1 = (x1 < zc) ? zc : x1;
+                if (inner) {
+                    double d = fabs(x1 - xi); const double psi = fabs(x1 - zc); if (psi > 1.) d *= (1. / psi);
+                    n1 += d;
+                    xout1[i] = x1;
+                }
+            }
+            ring[t % 3][prow][slot] = x1;
+        }
+        __syncthreads();
+        if (t >= 1 && inner) {
+            const int l = t - 1;
+            double xj[SLOTS];
+            xj[0] = (ap[0] != 0.) ? ring[(l + 2) % 3][wave][lane + 1] : 0.;
+            xj[1] = (ap[1] != 0.) ? ring[(l + 1) % 3][wave][lane + 1] : 0.;
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) xj[2 + k] = (ap[2 + k] != 0.) ? ring[l % 3][wave + DR[k]][lane + 1 + DC[k]] : 0.;
+            const double x1 = ring[l % 3][wave][lane + 1];
+            double x2 = bp;
+            #pragma unroll
+            for (int o = 0; o < SLOTS; ++o) { const int s = ORDER[o]; if (ap[s] != 0.) x2 -= ap[s] * xj[s]; }
+            if (l == 0) x2 = (x2 < zp) ? zp : x2;
+            double d = fabs(x2 - x1); const double psi = fabs(x2 - zp); if (psi > 1.) d *= (1. / psi);
+            n2 += d;
+            xout[(size_t)l * layer + i0] = x2;
+        }
+        #pragma unroll
+        for (int s = 0; s < SLOTS; ++s) ap[s] = ac[s];
+        bp = bc; zp = zc;
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) { n1 += __shfl_down(n1, off, 64); n2 += __shfl_down(n2, off, 64); }
+    if (lane == 0) { sm[0][wave] = n1; sm[1][wave] = n2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s1 = 0., s2 = 0.;
+        for (int w = 0; w <= W; ++w) { s1 += sm[0][w]; s2 += sm[1][w]; }
+        __hip_atomic_store(&part[blockIdx.x], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[2048 + blockIdx.x], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sLast = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+        if (sLast) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sLast) return;
+    double s1 = 0., s2 = 0.;
+    for (uint32_t k = threadIdx.x; k < gridDim.x; k += blockDim.x) { s1 += __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s2 += __hip_atomic_load(&part[2048 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    __syncthreads();
+    if (lane == 0) { sm[0][wave] = s1; sm[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) { double t1 = 0., t2 = 0.; for (int w = 0; w <= W; ++w) { t1 += sm[0][w]; t2 += sm[1][w]; } result[0] = t1 / g.N; result[1] = t2 / g.N; }
+}
+
 int main(int argc, char** argv)
 {
     const int NX = argc > 1 ? atoi(argv[1]) : 512, NY = argc > 2 ? atoi(argv[2]) : 512, NZ = 20;
@@ -325,6 +423,22 @@ int main(int argc, char** argv)
         size_t bad = 0; for (size_t i = 0; i < N; ++i) if (memcmp(&got[i], &ref[i], 8) != 0) ++bad;
         printf("%s: %d blocks of %d threads: %.1f us per pair, %zu of %zu values differ from two single sweeps\n", name, blocks, (W + 1) * 64, t, bad, N);
     };
+    {
+        const int W = 10, patchRows = (NY + (W - 2) - 1) / (W - 2), patchCols = (NX + 63) / 64, blocks = patchRows * patchCols;
+        double *dpart, *dres, *dx1b; unsigned* darr;
+        CHECK(hipMalloc(&dpart, 4096 * 8)); CHECK(hipMalloc(&dres, 16)); CHECK(hipMalloc(&darr, 4)); CHECK(hipMalloc(&dx1b, N * 8)); CHECK(hipMemset(darr, 0, 4));
+        if (blocks <= 2048) {
+            hipMemset(dy, 0, N * 8);
+            const float t = timeit([&] { hipLaunchKernelGGL(k_pair64_full<10>, dim3(blocks), dim3((W + 1) * 64), 0, 0, g, dx0, dx1b, dy, patchCols, dpart, darr, dres); }, 20);
+            hipMemcpy(got.data(), dy, N * 8, hipMemcpyDeviceToHost);
+            size_t bad = 0; for (size_t i = 0; i < N; ++i) if (memcmp(&got[i], &ref[i], 8) != 0) ++bad;
+            std::vector<double> r1(N); hipMemcpy(r1.data(), dx1b, N * 8, hipMemcpyDeviceToHost);
+            std::vector<double> s1(N); hipMemcpy(s1.data(), dx1, N * 8, hipMemcpyDeviceToHost);     // dx1 = first single sweep of the reference pair
+            size_t bad1 = 0; for (size_t i = 0; i < N; ++i) if (memcmp(&r1[i], &s1[i], 8) != 0) ++bad1;
+            double res[2]; hipMemcpy(res, dres, 16, hipMemcpyDeviceToHost);
+            printf("pair64 W=10 + z, own x, x' stored, two norms, last-block sum: %d blocks: %.1f us per pair; x'' differs in %zu, x' in %zu values; norms %.6e %.6e\n", blocks, t, bad, bad1, res[0], res[1]);
+        }
+    }
     run_pair64(k_pair64<10>, 10, "pair64 W=10");
     run_pair64(k_pair64<15>, 15, "pair64 W=15");
     run_pair64(k_pair64<6>, 6, "pair64 W=6");
