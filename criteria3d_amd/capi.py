@@ -147,6 +147,7 @@ SIGNATURES = {
     "sf3d_dist_prepare": (u8, [i32, i32]),
     "sf3d_dist_export": (u8, [vp]),
     "sf3d_dist_connect": (u8, [vp]),
+    "sf3d_get_regular_grid": (u8, [p32, p32, p32, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
     "sf3d_dist_owner": (u8, [i32, u32, u32, C.POINTER(C.c_int32)]),
     "sf3d_dist_halo": (u8, [i32, i32, i32, i32, u32, p32, p32]),
 }

@@ -359,6 +359,9 @@ sf3d_error_t sf3d_set_node_soil(uint32_t i, uint16_t soil, uint16_t horizon)   /
     NEED_INIT_E; NEED_NODE_E(i);
     if (M.surf[i]) return SF3D_INDEX_ERROR;
     if (soil >= soil1D.size() || horizon >= soil1D[soil].size()) return SF3D_PARAMETER_ERROR;
+    /* the index table outlives re-initialisation like the reference's (soilFluxes3D.cpp:39 is never cleared): an entry left
+     * from an earlier model points past the present soil list - the reference would store a dangling pointer there */
+    if (soil1D[soil][horizon] >= M.soils.size()) return SF3D_PARAMETER_ERROR;
     M.cls[i] = soil1D[soil][horizon]; M.hasClass[i] = 1;
     M.graphDirty = true;
     return SF3D_OK;
@@ -733,6 +736,62 @@ sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t*
     sf3d_error_t e = sf3d_compute_partition(M, 0, world, part);
     if (e != SF3D_OK) return e;
     for (uint32_t k = 0; k < count; ++k) out[k] = part.owner[first + k];
+    return SF3D_OK;
+}
+/* Is the node graph a regular NX x NY x NZ grid in the layer-major numbering i = (l NY + r) NX + c with the ten-link stencil
+ * (up, down, up to eight laterals to the 8-neighbourhood of the same layer)?  Host logic over the staged links; groundwork for
+ * the two-iterations-per-pass sweep, which needs exactly this structure.  dr/dc: row / column step of lateral
+ * slot k = 0..7 at a node that has all eight; nodes on the grid's edge have fewer laterals and fill their slots in their own
+ * order (setNodeLink puts the k-th lateral of a node into slot 2 + k), so a kernel decodes their steps from the link targets. */
+sf3d_error_t sf3d_get_regular_grid(uint32_t* nx, uint32_t* ny, uint32_t* nz, int8_t* dr, int8_t* dc)
+{
+    if (!M.initialized) return SF3D_MEMORY_ERROR;
+    if (!nx || !ny || !nz || !dr || !dc) return SF3D_PARAMETER_ERROR;
+    const uint64_t N = M.N, ns = M.ns;
+    if (ns == 0 || N % ns != 0) return SF3D_MISSING_DATA_ERROR;
+    const uint64_t NZ = N / ns;
+    int64_t maxOff = 0;                                    /* NX + 1: the diagonal step */
+    uint64_t full = N;                                     /* first node with eight laterals */
+    for (uint64_t i = 0; i < N; ++i) {
+        int cnt = 0;
+        for (int k = 0; k < 8; ++k) {
+            if (M.ltype[2 + k][i] == SF3D_LINK_NONE) continue;
+            ++cnt;
+            const int64_t o = llabs((int64_t)M.lto[2 + k][i] - (int64_t)i);
+            if (o > maxOff) maxOff = o;
+        }
+        if (cnt == 8 && full == N) full = i;
+    }
+    const int64_t NX = maxOff - 1;
+    if (full == N || NX < 2 || ns % (uint64_t)NX != 0) return SF3D_MISSING_DATA_ERROR;
+    const int64_t NY = (int64_t)(ns / (uint64_t)NX);
+    if (NY < 2) return SF3D_MISSING_DATA_ERROR;
+    auto decode = [&](int64_t off, int64_t& rr, int64_t& cc) {
+        rr = (off >= 0) ? (off + NX / 2) / NX : -((-off + NX / 2) / NX);
+        cc = off - rr * NX;
+        return rr >= -1 && rr <= 1 && cc >= -1 && cc <= 1 && !(rr == 0 && cc == 0);
+    };
+    for (uint64_t i = 0; i < N; ++i) {
+        const int64_t l = (int64_t)(i / ns), r = (int64_t)((i % ns) / (uint64_t)NX), c = (int64_t)(i % (uint64_t)NX);
+        if (M.ltype[0][i] != SF3D_LINK_NONE && (l == 0 || M.lto[0][i] != i - ns)) return SF3D_MISSING_DATA_ERROR;
+        if (M.ltype[1][i] != SF3D_LINK_NONE && (l == (int64_t)NZ - 1 || M.lto[1][i] != i + ns)) return SF3D_MISSING_DATA_ERROR;
+        unsigned seen = 0;
+        for (int k = 0; k < 8; ++k) {
+            if (M.ltype[2 + k][i] == SF3D_LINK_NONE) continue;
+            int64_t rr, cc;
+            if (!decode((int64_t)M.lto[2 + k][i] - (int64_t)i, rr, cc)) return SF3D_MISSING_DATA_ERROR;
+            if (r + rr < 0 || r + rr >= NY || c + cc < 0 || c + cc >= NX) return SF3D_MISSING_DATA_ERROR;
+            const unsigned bit = 1u << ((rr + 1) * 3 + (cc + 1));
+            if (seen & bit) return SF3D_MISSING_DATA_ERROR;              /* two links to the same neighbour */
+            seen |= bit;
+        }
+    }
+    *nx = (uint32_t)NX; *ny = (uint32_t)NY; *nz = (uint32_t)NZ;
+    for (int k = 0; k < 8; ++k) {
+        int64_t rr, cc;
+        decode((int64_t)M.lto[2 + k][full] - (int64_t)full, rr, cc);
+        dr[k] = (int8_t)rr; dc[k] = (int8_t)cc;
+    }
     return SF3D_OK;
 }
 sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32_t capacity, uint32_t* out, uint32_t* count)

@@ -369,6 +369,11 @@ sf3d_error_t sf3d_dist_prepare(int rank, int world);
 sf3d_error_t sf3d_dist_export(void* blob_out);
 sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
 /* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
+/* Host logic, no device needed: SF3D_OK and the shape if the staged node graph is a regular NX x NY x NZ grid in layer-major
+ * numbering i = (l NY + r) NX + c with the ten-link stencil (slot 0 up, 1 down, laterals to the 8-neighbourhood of the layer;
+ * dr[k], dc[k]: row / column step of lateral slot k at a node that has all eight - edge nodes fill their slots in their own order),
+ * SF3D_MISSING_DATA_ERROR otherwise (irregular DEM outlines, other numberings).  dr, dc: 8 entries each. */
+sf3d_error_t sf3d_get_regular_grid(uint32_t* nx, uint32_t* ny, uint32_t* nz, int8_t* dr, int8_t* dc);
 sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* owner_out);
 /* halo lists of `rank` in a world of `world`: direction 0 = nodes sent to `peer`, 1 = nodes received
  * from `peer` (sorted global indices; pass out = NULL to query the count) */
