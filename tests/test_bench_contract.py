@@ -67,3 +67,12 @@ def test_bench_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["work"]["accepted"] == 22
+
+
+def test_bench_reads_an_existing_pmc_summary():
+    """roofline.traffic comes from the committed rocprofv3 PMC summary bench.py names: the file must exist and carry the dominant kernel"""
+    import re
+    src = (ROOT / "bench.py").read_text()
+    name = re.search(r'"profiles" / "(r01_\w+_kernel_summary\.json)"', src).group(1)
+    prof = json.load(open(ROOT / "profiles" / name))
+    assert prof["k_sweep"]["hbm_traffic_MB"] > 0.5 * 152 * 5242880 / 1e6
