@@ -105,6 +105,7 @@ def build_oracle(with_reference: bool = True) -> None:
     if with_reference:
         _run(["make", "-C", str(ROOT / "oracle"), "ref"])
         _run(["make", "-C", str(ROOT / "oracle"), "ref-tuned"])
+        _run(["make", "-C", str(ROOT / "oracle"), "ref-ndebug"])
 
 
 def build_all(force: bool = False) -> None:

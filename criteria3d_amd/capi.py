@@ -342,6 +342,13 @@ def load_reference() -> SF3D:
     return SF3D(REFERENCE_LIB)
 
 
+def load_reference_ndebug() -> SF3D:
+    """The same unmodified sources built with -DNDEBUG (oracle/Makefile `ref-ndebug`): golden vectors with Urban / Road nodes."""
+    if QT_CORE.exists():
+        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)
+    return SF3D(REFERENCE_LIB.with_name("libsf3d_ref_ndebug.so"))
+
+
 def load_reference_tuned() -> SF3D:
     """The same unmodified sources built -O3 -march=x86-64-v3 (oracle/Makefile `ref-tuned`): CPU baseline timing only."""
     if QT_CORE.exists():

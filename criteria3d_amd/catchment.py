@@ -177,7 +177,7 @@ class Heat:
     advection: bool = False            # initializeHeatFlag(.., isComputeAdvectiveFlux, ..)
     latent: bool = True                # initializeHeatFlag(.., .., isComputeLatentHeat)
     save_mode: int = 2                 # heatFluxSaveMode_t: 0 None, 1 Total, 2 All
-    t0_surface: float = 288.15         # initial temperature at the top soil node [K] ...
+    t0_surface: float | None = 288.15  # initial temperature at the top soil node [K] (None: never call setNodeTemperature - setNode's 20 C default stays) ...
     t0_gradient: float = -2.0          # ... plus this many K per metre of depth below the surface
     height_wind: float = 2.0
     height_temperature: float = 2.0
@@ -249,7 +249,7 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
              "set_hydraulic_properties")
     sf.check(sf.lib.sf3d_set_numerical_parameters(*m.numerics), "set_numerical_parameters")
     sf.lib.sf3d_set_threads_number(threads)
-    if heat is not None:
+    if heat is not None and heat.t0_surface is not None:
         # temperatures first: with latent heat the conductivity set by the potential setters has a vapour term
         up = m.link_dir == capi.LINK_UP
         parent = np.arange(m.n)
@@ -322,6 +322,44 @@ def snapshot(sf: capi.SF3D, m: Model) -> dict:
         drainage=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_DRAINAGE),
         lateral=sf.lib.sf3d_get_total_boundary_water_flow(capi.BND_FREE_LATERAL_DRAINAGE),
     )
+
+
+LINK_FLOW_FIELDS = ("up", "down", "lateral_max", "lateral_sum", "lateral_in", "lateral_out")
+
+
+def link_flows(sf: capi.SF3D, m: Model, nodes=None) -> np.ndarray:
+    """[6][len(nodes)] per-link flow sums through the reference's getters (soilFluxes3D.cpp:1130-1230):
+    getNodeMaxWaterFlow(Up / Down / Lateral), getNodeSumLateralWaterFlow, ...In, ...Out."""
+    nodes = np.arange(m.n) if nodes is None else np.asarray(nodes)
+    L = sf.lib
+    out = np.empty((6, len(nodes)))
+    for k, i in enumerate(nodes):
+        i = int(i)
+        out[0, k] = L.sf3d_get_node_max_water_flow(i, capi.LINK_UP)
+        out[1, k] = L.sf3d_get_node_max_water_flow(i, capi.LINK_DOWN)
+        out[2, k] = L.sf3d_get_node_max_water_flow(i, capi.LINK_LATERAL)
+        out[3, k] = L.sf3d_get_node_sum_lateral_water_flow(i)
+        out[4, k] = L.sf3d_get_node_sum_lateral_water_flow_in(i)
+        out[5, k] = L.sf3d_get_node_sum_lateral_water_flow_out(i)
+    return out
+
+
+def urban_road_model(nx: int = 16, ny: int = 16, nz: int = 5) -> Model:
+    """Tilted catchment whose top soil layer carries Urban (infiltration x 0.33) and Road (no infiltration) boundary
+    types in two patches (water.cpp:504-513); their boundary flow is 0 (water.cpp:796-799 built -DNDEBUG)."""
+    m = catchment_model(nx, ny, nz)
+    ns = m.ns
+    r, c = np.divmod(np.arange(ns), nx)
+    top = ns + np.arange(ns)
+    free = m.btype[top] == capi.BND_NONE
+    urban = free & (r >= 2) & (r < ny // 2) & (c >= 2) & (c < nx // 2 + 2)
+    road = free & (r >= ny // 2 + 1) & (r < ny - 2) & (c >= nx // 3) & (c < nx - 2)
+    m.btype[top[urban]] = capi.BND_URBAN
+    m.btype[top[road]] = capi.BND_ROAD
+    m.bslope[top[urban | road]] = 0.0
+    m.barea[top[urban | road]] = m.cell_area
+    m.meta = dict(kind="urban_road", urban=int(urban.sum()), road=int(road.sum()))
+    return m
 
 
 def ragged_model(nx: int = 7, ny: int = 6, nz: int = 4, cell: float = 5.0) -> Model:

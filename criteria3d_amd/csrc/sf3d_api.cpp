@@ -139,6 +139,7 @@ bool needFlows()
 }
 
 template <class T> void reset(std::vector<T>& v, size_t n) { v.assign(n, T()); }
+bool needHeatState();
 
 #define NEED_INIT_E   if (!M.initialized) return SF3D_MEMORY_ERROR
 #define NEED_NODE_E(i) if ((i) >= M.N) return SF3D_INDEX_ERROR
@@ -332,6 +333,11 @@ sf3d_error_t sf3d_set_node(uint32_t i, double x, double y, double z, double v, i
     M.surf[i] = isSurf != 0;
     sf3d_set_node_boundary(i, bt, slope, barea);
     if (M.water) { M.pond[i] = isSurf ? 0.0001f : SF3D_NODATA; M.sink[i] = 0.; M.pondDirty = M.sinkDirty = true; }
+    if (M.heat && !isSurf) {                                        /* :620-626: soil nodes start at 20 degrees C */
+        needHeatState();
+        M.temperature[i] = 273.15 + 20; M.heatSink[i] = 0.;
+        M.heatStateDirty = M.heatSinkDirty = true;
+    }
     M.graphDirty = true;
     return SF3D_OK;
 }
@@ -498,6 +504,7 @@ static bool needHeat()
         if (dev().fetch_heat(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
     return true;
 }
+namespace { bool needHeatState() { return needHeat(); } }
 sf3d_error_t sf3d_set_node_heat_sink_source(uint32_t i, double v) { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; M.heatSink[i] = v; M.heatSinkDirty = true; return SF3D_OK; }
 sf3d_error_t sf3d_set_node_temperature(uint32_t i, double v)
 { NEED_INIT_E; NEED_NODE_E(i); HEAT_OFF_E; needHeat(); M.temperature[i] = v; M.heatStateDirty = true; return SF3D_OK; }
@@ -574,11 +581,14 @@ double sf3d_compute_step(double maxDt)                               /* soilFlux
 {
     if (!M.water && !M.heat) return std::min(maxDt, P.dtMax);
     if (!M.initialized || !M.solverReady) { fprintf(stderr, "sf3d: computeStep before initializeSF3D\n"); return std::nan(""); }
+    if (dev().fatal()) { fprintf(stderr, "sf3d: computeStep refused after a fatal device failure: %s\n", dev().last_error()); return std::nan(""); }
     double dt = std::nan("");
     sf3d_error_t e = dev().step(M, P, maxDt, &dt);
-    if (e != SF3D_OK && !(dt == dt)) {
-        fprintf(stderr, "sf3d: computeStep failed on the HIP device: %s\n", dev().last_error());
-        return std::nan("");
+    if (e != SF3D_OK) {
+        /* the reference's computeStep ignores run()'s error code (soilFluxes3D.cpp:1796) and returns the dt of a stepNan attempt;
+         * so does this one - after saying so - unless the device itself failed (no dt, peer time-out, heat step not started) */
+        fprintf(stderr, "sf3d: computeStep: %s\n", dev().last_error());
+        if (!(dt == dt) || dev().fatal()) return std::nan("");
     }
     return dt;
 }

@@ -112,6 +112,9 @@ public:
     void push_ctrl() { ctrlEdited_ = true; }
     bool ready() const { return built_; }
     const char* last_error() const { return err_; }
+    /* true after a failure that leaves the device state unusable (peer time-out of the multi-GPU exchange, a heat step that
+     * did not start, a HIP error): computeStep then refuses to go on instead of stalling once more per call */
+    bool fatal() const { return fatal_; }
     /* multi-GPU */
     sf3d_error_t dist_prepare(int rank, int world);
     sf3d_error_t dist_export(HostModel& m, const ParamsHost& p, DistBlob* out);
@@ -133,6 +136,7 @@ private:
     bool built_ = false, ctrlEdited_ = false;
     int world_ = 1, rank_ = 0;
     bool connected_ = false;
+    bool fatal_ = false;
     char err_[256] = {0};
     friend struct Impl;
 };

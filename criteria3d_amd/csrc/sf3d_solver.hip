@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -1586,10 +1587,14 @@ struct DeviceSolver::Impl {
     double ms[KID_COUNT] = {0};
 };
 
+/* on failure: message, then drain the solver stream (async copies from pageable host vectors may still be in flight and the
+ * caller is free to modify those vectors as soon as we return), mark the solver unusable, return */
 #define HIP_TRY(expr)                                                                          \
     do { hipError_t e_ = (expr);                                                               \
          if (e_ != hipSuccess) {                                                               \
              snprintf(err_, sizeof(err_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+             if (impl_ && impl_->stream) (void)hipStreamSynchronize(impl_->stream);           \
+             fatal_ = true;                                                                    \
              return SF3D_SOLVER_ERROR; } } while (0)
 
 DeviceSolver& DeviceSolver::instance() { static DeviceSolver s; return s; }
@@ -1625,6 +1630,7 @@ sf3d_error_t DeviceSolver::release()
     I.devDist = nullptr;
     connected_ = false;
     built_ = false;
+    fatal_ = false;
     return SF3D_OK;
 }
 
@@ -1679,7 +1685,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             if ((m.surf[i] != 0) != (i < ns)) { snprintf(err_, sizeof(err_), "node %u: surface nodes must be exactly the first nrSurfaceNodes indices", i); return SF3D_TOPOGRAPHY_ERROR; }
             if (!m.hasClass[i]) { snprintf(err_, sizeof(err_), "node %u has no soil/surface class", i); return SF3D_MISSING_DATA_ERROR; }
         }
-        if (world_ > 1 && connected_) { snprintf(err_, sizeof(err_), "topology changed after sf3d_dist_connect: export/connect again"); }
+        if (world_ > 1 && connected_) { snprintf(err_, sizeof(err_), "topology changed after sf3d_dist_connect: call sf3d_dist_prepare / export / connect again"); return SF3D_TOPOGRAPHY_ERROR; }
         /* pull anything newer on the device before the arrays are re-created */
         if (built_) { if (m.hostStaleState) fetch_state(m); if (m.hostStaleFlows) fetch_flows(m); if (m.heat && m.hostStaleHeat && I.v.heat.on) fetch_heat(m); }
         release();
@@ -1696,7 +1702,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         std::vector<uint8_t> kind(NS, LK_NONE);
         std::vector<double> dist(NS, 0.), area(NS, 0.);
         std::vector<uint32_t> to(NS, 0u);
-        bool bad = false;
+        std::atomic<bool> bad{false};
         parallel_for(N, [&](uint32_t a, uint32_t b) {
             for (uint32_t i = a; i < b; ++i) {
                 const int nl = m.nLat[i];
@@ -2615,7 +2621,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (c.hSweepsLast > 0) I.lastHeatSweeps = c.hSweepsLast;
             if (getenv("SF3D_HEAT_DEBUG") && getenv("SF3D_HEAT_DEBUG")[0] == '2') fprintf(stderr, "gpu heatLoop stage %u next dt %g outer %g/%g sweeps %u MBR %.6e storage %.12e sink %.6e courant %.6e\n", c.hStage, c.hDt, c.hOuterDt, c.hOuterSum, c.hSweepsLast, c.heatCur.MBR, c.heatCur.storage, c.heatCur.sinkSource, c.hCourant);
             if (c.hStage == HS_FINISHED) { I.lastHeatSteps = c.hRows + c.hPad; break; }
-            if (c.hStage == HS_IDLE) { snprintf(err_, sizeof(err_), "heat step did not start (water stage %u)", c.stage); stage = ST_FAIL; break; }
+            if (c.hStage == HS_IDLE) { snprintf(err_, sizeof(err_), "heat step did not start (water stage %u)", c.stage); stage = ST_FAIL; fatal_ = true; break; }
             if (++hguard > 1000000) { snprintf(err_, sizeof(err_), "heat state machine did not terminate (stage %u)", c.hStage); return SF3D_SOLVER_ERROR; }
         }
         if (getenv("SF3D_HEAT_DEBUG")) fprintf(stderr, "heat: water dt %g: %u heat steps accepted, %u halved, last dt %g, last sweeps %u, courant %g, MBR %g\n", I.hostCtrl->dtWater, I.hostCtrl->hRows, I.hostCtrl->hPad, I.hostCtrl->hDt, I.hostCtrl->hSweepsLast, I.hostCtrl->hCourant, I.hostCtrl->heatCur.MBR);
@@ -2625,7 +2631,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         HIP_TRY(hipStreamSynchronize(st));
     }
     mirror_ = *I.hostCtrl;
-    if (mirror_.distError) snprintf(err_, sizeof(err_), "rank %d: a peer did not answer within the bounded wait (multi-GPU exchange)", rank_);
+    if (mirror_.distError) { snprintf(err_, sizeof(err_), "rank %d: a peer did not answer within the bounded wait (multi-GPU exchange)", rank_); fatal_ = true; }
+    else if (stage != ST_ACCEPT && !fatal_) snprintf(err_, sizeof(err_), "the mass balance is not a number at the minimum time step (stepNan, cpusolver.cpp:176-180): state left as the reference leaves it");
     p.dtCurr = mirror_.dtCurr;
     *dtOut = mirror_.dt;
     m.hostStaleState = true;

@@ -247,6 +247,48 @@ def heat_advection_steps(sf, threads=1):
     return {k: np.array(v) for k, v in out.items()}
 
 
+def _flow_hours(sf, m, plan, threads=1, sinks_fn=None, pre=None):
+    """like _hours, plus the per-link flow sums of every node after the last hour (acceptStep / updateLinkFlux,
+    water.cpp:230-277, read through getNodeMaxWaterFlow / getNodeSumLateralWaterFlow[In|Out])"""
+    out = _hours(sf, m, plan, threads, sinks_fn=sinks_fn, pre=pre)
+    out["link_flows"] = cm.link_flows(sf, m)
+    out["boundary_flow"] = sf.boundary_water_flow(0, m.n)
+    return out
+
+
+def flows_c2_f20(sf, threads=1):
+    """C2 F20, two hours (35 accepted steps): flow sums of the infiltration regime - no link is ever dropped below the surface"""
+    m = cm.catchment_model(64, 64, 10)
+    return _flow_hours(sf, m, [(20.0, None, False), (0.0, None, True)], threads)
+
+
+def flows_c2_f60(sf, threads=1):
+    """C2 F60, hour 0 and 150 steps of hour 1: runoff links switch on and off (dropped links: quirk 1), Courant rejections
+    assemble surface rows only, every step of hour 1 ends in restoreBestStep"""
+    m = cm.catchment_model(64, 64, 10)
+    return _flow_hours(sf, m, [(60.0, None, False), (0.0, 150, True)], threads)
+
+
+def flows_ragged(sf, threads=1):
+    """the ragged graph (holes, short columns, mixed slot orders) with rain, evaporation and uptake"""
+    m = cm.ragged_model()
+    return _flow_hours(sf, m, [(0, None, False), (0, None, False), (0, None, True)], threads, sinks_fn=_ragged_sinks, pre=_ragged_pre)
+
+
+def urban_road(sf, threads=1):
+    """Urban / Road top-soil nodes (reference built -DNDEBUG, quirk 9): 30 mm then a dry hour"""
+    m = cm.urban_road_model()
+    return _flow_hours(sf, m, [(30.0, None, True), (0.0, 200, True)], threads)
+
+
+def heat_default_temperature(sf, threads=1):
+    """water + heat + latent heat on the column WITHOUT any setNodeTemperature call: the soil starts at setNode's default of
+    20 degrees C (soilFluxes3D.cpp:620-626), as it does for the reference's own caller"""
+    m = cm.with_heat_surface(cm.column_model(22, 0.05, 1.0))
+    return _heat_hours(sf, m, cm.Heat(water=True, latent=True, save_mode=1, t0_surface=None), [(1.0 if h == 0 else 0.0, h in (0, 2)) for h in range(3)],
+                       threads, flux_nodes=(1, 2, 10, 21))
+
+
 SCENARIOS = {
     "c1_column": c1_column,
     "c1_column_period": c1_column_period,
@@ -266,7 +308,18 @@ SCENARIOS = {
     "heat_catchment_latent": heat_catchment_latent,
     "heat_advection_steps": heat_advection_steps,
     "heat_water_table": heat_water_table,
+    "heat_default_temperature": heat_default_temperature,
+    "flows_c2_f20": flows_c2_f20,
+    "flows_c2_f60": flows_c2_f60,
+    "flows_ragged": flows_ragged,
+    "urban_road": urban_road,
 }
+# which build of the unmodified reference generates the vector: "ndebug" = the same sources with -DNDEBUG (quirk 9: Urban / Road
+# nodes reach assert(false) in updateBoundaryWaterData otherwise); everything else comes from the project-flags build
+REFERENCE_VARIANT = {"urban_road": "ndebug"}
+# scenarios whose per-link flow sums depend on quirk 1 (stale matrix slot read for dropped links): the reference's vector is
+# matched with SF3D_COMPAT_STALE_LINK_FLOW=1
+COMPAT_SCENARIOS = ("flows_c2_f20", "flows_c2_f60", "flows_ragged", "urban_road")
 HEAT_SCENARIOS = tuple(k for k in SCENARIOS if k.startswith("heat_"))
 
 
