@@ -165,6 +165,7 @@ sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h
     sf3d_error_t c = sf3d_clean();
     if (c != SF3D_OK) return c;
     M.water = w != 0; M.heat = h != 0; M.solutes = s != 0;
+    { const char* ce = getenv("SF3D_COMPAT_STALE_LINK_FLOW"); M.compat = ce && ce[0] == '1'; }
     if (M.heat) { HF.vapor = true; HF.advection = true; HF.save = saveMode; }        /* :58-65 */
     M.heatVapor = HF.vapor; M.heatAdvection = HF.advection; M.heatSave = HF.save;
     M.N = n; M.ns = ns;

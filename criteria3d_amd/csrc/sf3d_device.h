@@ -126,6 +126,11 @@ struct Ctrl {
     double heatPeriodSink;    /* balanceDataCurrentPeriod.heatSinkSource                                 */
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
+    /* ---- quirk-1 compat (SF3D_COMPAT_STALE_LINK_FLOW=1): which assembly k_compat_rows has to mirror into the emulated row storage ---- */
+    uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
+    uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */
+    uint32_t compatSeq;       /* last assembly mirrored                                                            */
+    uint32_t compatPad;
     /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
     uint64_t counters[8];
 };
@@ -225,6 +230,12 @@ struct DevView {
     double *b, *C;
     double* X[SF3D_POOL];
     double *Se, *SeHold, *K, *flow, *bflowRate, *bflowSum;   /* SeHold = Se(Hold), written at approximation 0 */
+    /* quirk-1 compat, null unless SF3D_COMPAT_STALE_LINK_FLOW=1: the reference's compacted row storage matrixA.values[row][0..10]
+     * (compatCv[c][row]) and numColsInRow (compatCn), shared by the water and the heat assembly, mirrored write for write so that
+     * the slot a dropped link's search falls into (cpusolver.h:42-52) holds what it holds in the reference; compatDiag: the
+     * diagonal of the row k_assemble has just written UN-normalised (k_compat_rows normalises after the Courant decision, like
+     * the reference's separate preconditioning pass) */
+    double* compatCv; uint8_t* compatCn; double* compatDiag;
     double *part0, *part1;              /* per-block partials [nb] */
     unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
     const SoilDev* soils;

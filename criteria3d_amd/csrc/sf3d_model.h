@@ -33,6 +33,7 @@ struct ParamsHost {                    /* SolverParameters, types.h:291-315 (per
 struct HostModel {
     bool initialized = false, solverReady = false;
     bool water = true, heat = false, solutes = false;
+    bool compat = false;             /* SF3D_COMPAT_STALE_LINK_FLOW=1 at sf3d_initialize: reproduce quirk 1's stale-slot reads */
     uint32_t N = 0, ns = 0;
     std::vector<double> x, y, z, size;
     std::vector<uint8_t> surf, hasClass;

@@ -451,6 +451,7 @@ __device__ __forceinline__ void courant_decision(Ctrl* c, double cmax)
 {
     c->counters[2]++;
     c->courant = cmax;
+    c->asmSeq++; c->asmSurfOnly = (cmax < 1.01 || c->dt <= c->dtMin) ? 0u : 1u;
     if (cmax < 1.01 || c->dt <= c->dtMin) {
         uint32_t budget = (uint32_t)((c->approx + 1) * ((float)c->maxIter / (float)c->maxApprox));
         c->iterBudget = budget > 25u ? budget : 25u;
@@ -957,7 +958,9 @@ __device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& c
                                             double sum, double Hoi, double dt, double invariantFlux, double Ci, double flowi)
 {
     const double cdt = Ci / dt;
-    const double inv = 1.0 / (cdt + sum);
+    const bool raw = v.compatDiag != nullptr;          /* compat: row stored un-normalised, k_compat_rows scales it after the Courant decision */
+    const double inv = raw ? 1.0 : 1.0 / (cdt + sum);  /* (x * 1.0 is exact) */
+    if (raw) v.compatDiag[i] = cdt + sum;
     #pragma unroll
     for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
         k[2 * p] = (k[2 * p] * -1.) * inv; k[2 * p + 1] = (k[2 * p + 1] * -1.) * inv;
@@ -1164,6 +1167,83 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_
     }
 }
 
+/* quirk-1 compat only.  Mirrors the assembly that has just been decided into the emulated row storage of the reference
+ * (computeLinearSystemElement cpusolver.cpp:348-389: every existing link writes its conductance at the running column, only a
+ * non-zero one advances it; columns [1, numCols) negated, [0] = diagonal) and then does what the reference's separate
+ * preconditioningMatrix pass does (:284-305) - unless the Courant check refused the attempt, in which case the reference had
+ * assembled the surface rows only and left them un-normalised. */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_compat_rows(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->asmSeq == c->compatSeq) return;
+    const bool surfOnly = c->asmSurfOnly != 0;
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    const size_t N = v.N;
+    FOR_EACH_CHUNK_IN(v, 0u, surfOnly ? v.nListSurf : v.nList) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (NOT_MINE(v, i) || (surfOnly && i >= v.ns)) continue;
+        const ChunkDesc cd = v.cdesc[q];
+        double a[SF3D_SLOTS];
+        #pragma unroll
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = v.A2[(size_t)p * N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+        const double diag = v.compatDiag[i];
+        const double inv = surfOnly ? 1.0 : 1.0 / diag;
+        uint32_t col = 1; bool lastDropped = false;
+        #pragma unroll
+        for (int o = 0; o < SF3D_SLOTS; ++o) {
+            const uint32_t s = order[o];
+            const bool exists = (cd.kind[s] == CK_MIXED) ? v.lkind[(size_t)s * N + i] != LK_NONE : cd.kind[s] != CK_NONE;
+            if (!exists) continue;
+            lastDropped = !(a[s] != 0.);                       /* a = k * -1: -0.0 for a dropped link */
+            if (!lastDropped) { v.compatCv[(size_t)col * N + i] = a[s] * inv; ++col; }
+        }
+        if (lastDropped) v.compatCv[(size_t)col * N + i] = 0.0;   /* the conductance itself, written and never negated */
+        v.compatCn[i] = (uint8_t)col;
+        v.compatCv[i] = surfOnly ? diag : 1.0;
+        if (!surfOnly) {
+            #pragma unroll
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { sf3d_d2 t; t.x = a[2 * p] * inv; t.y = a[2 * p + 1] * inv; v.A2[(size_t)p * N + i] = t; }
+            v.b[i] *= inv;
+        }
+    }
+    __syncthreads();
+    if (!arrive_last(v, 0., 0., false)) return;
+    if (threadIdx.x == 0) c->compatSeq = c->asmSeq;
+}
+
+/* acceptStep's link flow sums for one row (water.cpp:240-250 + updateLinkFlux :269-277): the stored, row-normalised coefficient as in
+ * the reference.  A zero coefficient adds exactly 0 - unless the compat storage exists: then a dropped
+ * link reads the slot after the row's last column, like getMatrixElementValue (cpusolver.h:42-52). */
+template <bool NT>
+__device__ __forceinline__ void accept_links_row(const DevView& v, uint32_t q, uint32_t i, const double* __restrict__ X, double dt)
+{
+    const sf3d_d2* __restrict__ A2 = v.A2;
+    double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
+    uint32_t j[SF3D_SLOTS];
+    #pragma unroll
+    for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }   /* non-zero only where a link exists */
+    const ChunkDesc cd = v.cdesc[q];
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) {
+        if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
+        else j[s] = i + cd.delta[s];
+    }
+    if (v.compatCv != nullptr) {
+        const double stale = v.compatCv[(size_t)v.compatCn[i] * v.N + i] * v.compatCv[i];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            const bool exists = (cd.kind[s] == CK_MIXED) ? v.lkind[(size_t)s * v.N + i] != LK_NONE : cd.kind[s] != CK_NONE;
+            if (exists && !(a[s] != 0.)) a[s] = stale;
+        }
+    }
+    const double Hi = X[i];
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? load_stream<NT>(&v.lflowSum[(size_t)s * v.N + i]) : 0.; }
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s)
+        if (a[s] != 0.) store_stream<NT>(&v.lflowSum[(size_t)s * v.N + i], f[s] + a[s] * (Hi - xj[s]) * dt);
+}
+
 /* JacobiWaterCPU, water.cpp:565-601.
  * All coefficient loads, then all neighbour gathers, are issued before the ordered accumulation
  * so that ~30 independent loads per lane are in flight (HBM-bound kernel, 152 algorithmic B/node). */
@@ -1368,35 +1448,18 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     if (threadIdx.x == 0) restore_decision(v.ctrl, vals[0], vals[1]);
 }
 
-/* acceptStep flow sums, water.cpp:240-250 + updateLinkFlux :269-277 (stored, row-normalised
- * coefficient as in the reference; a zero coefficient adds exactly 0) */
+/* acceptStep flow sums, water.cpp:240-250 + updateLinkFlux :269-277 */
 template <bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
 {
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_ACCEPT) return;
     const double* __restrict__ X = v.X[c->cur];
-    const sf3d_d2* __restrict__ A2 = v.A2;
     const double dt = c->dt;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
-        double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
-        uint32_t j[SF3D_SLOTS];
-        #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }   /* non-zero only where a link exists */
-        const ChunkDesc cd = v.cdesc[q];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) {
-            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
-            else j[s] = i + cd.delta[s];
-        }
-        const double Hi = X[i];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? load_stream<NT>(&v.lflowSum[(size_t)s * v.N + i]) : 0.; }
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s)
-            if (a[s] != 0.) store_stream<NT>(&v.lflowSum[(size_t)s * v.N + i], f[s] + a[s] * (Hi - xj[s]) * dt);
+        accept_links_row<NT>(v, q, i, X, dt);
         if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
     }
 }
@@ -1420,27 +1483,11 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept_links(DevView v)
 {
     const Ctrl* c = v.ctrl;
     const double* __restrict__ X = v.X[c->acceptBuf];
-    const sf3d_d2* __restrict__ A2 = v.A2;
     const double dt = c->acceptDt;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
-        double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
-        uint32_t j[SF3D_SLOTS];
-        #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = load_coeff<NT>(&A2[(size_t)p * v.N + i]); a[2 * p] = t.x; a[2 * p + 1] = t.y; }
-        const ChunkDesc cd = v.cdesc[q];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) {
-            if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
-            else j[s] = i + cd.delta[s];
-        }
-        const double Hi = X[i];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) { xj[s] = X[j[s]]; f[s] = (a[s] != 0.) ? load_stream<NT>(&v.lflowSum[(size_t)s * v.N + i]) : 0.; }
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s)
-            if (a[s] != 0.) store_stream<NT>(&v.lflowSum[(size_t)s * v.N + i], f[s] + a[s] * (Hi - xj[s]) * dt);
+        accept_links_row<NT>(v, q, i, X, dt);
     }
 }
 
@@ -1631,6 +1678,8 @@ sf3d_error_t DeviceSolver::release()
     connected_ = false;
     built_ = false;
     fatal_ = false;
+    /* the SF3D_* mode switches are read again when the next model is built (tests toggle them between models of one process) */
+    I.overlapAccept = I.useFused = I.useGraphs = I.fuseFirstSweep = I.residentGrids = -1;
     return SF3D_OK;
 }
 
@@ -1946,6 +1995,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             I.pushBlocks = (maxSend + SF3D_BLOCK - 1) / SF3D_BLOCK;
             if (I.pushBlocks == 0) I.pushBlocks = 1;
             if (I.pushBlocks > 256) I.pushBlocks = 256;
+        }
+        if (m.compat) {      /* quirk-1 emulation: calloc'd like the reference's rows (soilFluxes3D.cpp:76-155) */
+            HIP_TRY(dev_alloc(I.allocs, v.compatCv, (size_t)N * (SF3D_SLOTS + 2))); HIP_TRY(hipMemset(v.compatCv, 0, (size_t)N * (SF3D_SLOTS + 2) * 8));
+            HIP_TRY(dev_alloc(I.allocs, v.compatCn, N)); HIP_TRY(hipMemset(v.compatCn, 0, N));
+            HIP_TRY(dev_alloc(I.allocs, v.compatDiag, N)); HIP_TRY(hipMemset(v.compatDiag, 0, (size_t)N * 8));
         }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
@@ -2355,7 +2409,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
     if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
     if (I.fuseFirstSweep < 0) { const char* e = getenv("SF3D_FUSE_FIRST_SWEEP"); I.fuseFirstSweep = (e && e[0] == '1') ? 1 : 0; }   /* measured slower: off */
-    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn;      /* k_assemble also does the first Jacobi iteration */
+    const bool compat = v.compatCv != nullptr;   /* quirk-1 emulation: rows are stored raw and normalised by k_compat_rows after the Courant decision */
+    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat;      /* k_assemble also does the first Jacobi iteration */
     /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
      * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
      * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
@@ -2441,6 +2496,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
+        if (withHead && compat) hipLaunchKernelGGL(k_compat_rows, grid, block, 0, st, v);
         uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
