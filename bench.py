@@ -13,6 +13,13 @@ are timed, with the hour's sinks already resident in HBM (sf3d_synchronize() upl
 before the clock starts); a barrier + device synchronize brackets the timed region and the MAX
 over ranks is reported.  `value` = K simulated hours / that time.
 
+The timed region is repeated REPS times (default 3), each from a freshly rebuilt initial state, and the MEDIAN elapsed time
+is reported (`value`, `ms_per_step`; all repetitions in `repeats_s`).  `headline_6h` is the same measurement restricted to the
+timed hours 0-5 - the 6-hour figure SURVEY.md 8d quotes - whenever K >= 6, so that it is driver-timed whatever K is.
+`inclusive_value` puts the hourly sink/source upload (host -> HBM) inside the clock; it is never `value`.
+`python bench.py --gpus N` without a launcher spawns its own N ranks (fresh child processes, before anything touches the
+GPU) and relays rank 0's line.
+
 Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes per launch over
 its HIP-event duration measured on the solver's own stream) and `cpu_baseline` (rank 0, N=1:
 the unmodified reference built in oracle/_ref - or the oracle port when it cannot be loaded -
@@ -37,18 +44,22 @@ WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
              "C5": (519, 1208, 15)}       # the Ravone DEM itself (tests/golden/ravone_dem_519x1208.npz, 422 282 valid cells of 4 m)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
-ALGO_BYTES = {"k_sweep": 152, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
+# k_sweep_pair: two Jacobi iterations per launch, priced as the two sweeps it replaces (2 x 152 B/node)
+ALGO_BYTES = {"k_sweep": 152, "k_sweep_pair": 304, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, heat=None):
-    """Run `hours` simulated hours; return wall seconds spent inside the computeStep loops."""
+def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, heat=None, per_hour=None, inclusive=None):
+    """Run `hours` simulated hours; return wall seconds spent inside the computeStep loops.
+    per_hour: list receiving each hour's seconds; inclusive: one-element list accumulating the seconds with the hourly input
+    upload (sink/source array, atmosphere) inside the clock."""
     total = 0.0
     for h in range(hours):
         mm = cm.FORCINGS[forcing](h)
+        ti = time.perf_counter()
         sf.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(mm, model.cell_area)))
         if heat is not None:
             cm.apply_heat_forcing(sf, model, h)                     # hourly atmosphere at the HeatSurface nodes
@@ -65,8 +76,56 @@ def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, he
             if per_step is not None:
                 per_step.append((time.perf_counter(), dt))
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
-        total += time.perf_counter() - t0
+        t1 = time.perf_counter()
+        total += t1 - t0
+        if per_hour is not None:
+            per_hour.append(t1 - t0)
+        if inclusive is not None:
+            inclusive[0] += t1 - ti
     return total
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them) BEFORE this process touches torch or the GPU, relay rank 0's JSON line, exit with the
+    worst return code.  Nothing is exec'd from a process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=600)
+        except subprocess.TimeoutExpired:
+            p.kill(); p.wait()
+        if p.returncode != 0 and worst == 0:
+            worst = p.returncode
+    if worst != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    sys.exit(worst)
 
 
 def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0, threads=32):
@@ -127,6 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed region, each from a fresh initial state; the median is reported")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (best measured: 16-32)")
     args = ap.parse_args()
@@ -134,10 +194,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])          # does not return
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            log(f"[bench] --gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks")
-            sys.exit(2)
+        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU (or call without a launcher: bench.py spawns its own ranks)")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -145,6 +206,10 @@ def main():
 
     if not torch.cuda.is_available():
         log("[bench] no GPU visible: the product path has no CPU fallback")
+        sys.exit(3)
+    if os.environ.get("SF3D_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() <= local_rank:
+        log(f"[bench] rank {rank}: local rank {local_rank} has no GPU of its own ({torch.cuda.device_count()} visible); "
+            "SF3D_BENCH_SHARE_GPU=1 runs every rank on GPU 0 for functional tests")
         sys.exit(3)
     # one rank per GPU; SF3D_BENCH_SHARE_GPU=1 (functional testing on a 1-GPU box) puts every rank on
     # device 0 and uses gloo for the control plane, because RCCL refuses two ranks on one device
@@ -203,22 +268,37 @@ def main():
     # HIP events around the dominant kernel only, on every 8th computeStep (mode 2); --time-all-kernels
     # instruments every node kernel of every step (eager launches, ~6 % slower)
     sf.check(sf.lib.sf3d_kernel_timing(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2)), "kernel_timing")
-    per_step, hour_starts = [], []
-    barrier()
-    torch.cuda.synchronize()
-    c0 = sf.counters()
-    elapsed = run_hours(sf, cm, model, args.forcing, args.steps, per_step=per_step, hour_starts=hour_starts, heat=heat)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    c1 = sf.counters()
+    reps = max(1, args.reps)
+    rep_elapsed, rep_hours, rep_incl = [], [], []
+    per_step, hour_starts, c0 = [], [], None
+    for rep in range(reps):
+        if rep > 0:
+            sf.check(sf.lib.sf3d_kernel_timing(0), "kernel_timing")      # event statistics come from the first repetition only
+            fresh()
+        ps, hs_, ph, incl = [], [], [], [0.0]
+        barrier()
+        torch.cuda.synchronize()
+        if rep == 0:
+            c0 = sf.counters()
+        el = run_hours(sf, cm, model, args.forcing, args.steps, per_step=ps, hour_starts=hs_, heat=heat, per_hour=ph, inclusive=incl)
+        torch.cuda.synchronize()
+        if rep == 0:
+            c1 = sf.counters()
+            stats = sf.kernel_stats()
+            per_step, hour_starts = ps, hs_
+        vals = [el, incl[0], sum(ph[:6])] + ph
+        if world > 1:
+            dist.barrier()
+            t = torch.tensor(vals, dtype=torch.float64, device="cpu" if share else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            vals = [float(x) for x in t.tolist()]
+        rep_elapsed.append(vals[0]); rep_incl.append(vals[1]); rep_hours.append(vals[2])
+    order = sorted(range(reps), key=lambda k: rep_elapsed[k])
+    med = order[reps // 2]
+    elapsed, elapsed_incl, elapsed_6h = rep_elapsed[med], rep_incl[med], sorted(rep_hours)[reps // 2]
     tw = sf.lib.sf3d_get_total_water_content()
     if not np.isfinite(tw):     # computeStep keeps returning a dt after stepNan, like the reference: such a run measures nothing
         raise RuntimeError(f"rank {rank}: the state is not finite after the timed steps (total water content {tw}): invalid run")
-    stats = sf.kernel_stats()
     sf.lib.sf3d_kernel_timing(0)
 
     if rank != 0:
@@ -235,11 +315,18 @@ def main():
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs
     # of this same command, corrected per MI355X_MICROARCH.md: 2 x FETCH_SIZE + WRITE_SIZE); bench.py
     # cannot collect counters itself
-    traffic = None
+    traffic, traffic_source = None, None
     try:
-        prof = json.load(open(ROOT / "profiles" / "r01_k_kernel_summary.json"))
-        if world == 1 and args.workload == "C4" and dom in prof and "hbm_traffic_MB" in prof[dom]:
-            traffic = prof[dom]["hbm_traffic_MB"] * 1e6
+        for tag in ("r02_a", "r01_k"):
+            f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
+            if not f.exists():
+                continue
+            prof = json.load(open(f))
+            tuned = os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")
+            if world == 1 and args.workload == "C4" and not tuned and dom in prof and "hbm_traffic_MB" in prof[dom]:
+                traffic = prof[dom]["hbm_traffic_MB"] * 1e6
+                traffic_source = f"stored profile profiles/{f.name} (rocprofv3 --pmc passes of this command; not measured in this run)"
+            break
     except Exception:  # noqa: BLE001
         pass
     if dom and stats[dom][0] > 0:
@@ -248,7 +335,7 @@ def main():
         avg_s = ms / 1e3 / launches
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                     "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
                     "kernels": {k: {"launches": v[0], "total_ms": v[1],
                                     "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
@@ -259,6 +346,8 @@ def main():
             cpu = cpu_baseline(cm, capi, model, args.forcing, args.workload,
                                (hour_starts[0], per_step) if hour_starts else None, budget_s=args.cpu_budget,
                                threads=args.cpu_threads)
+            if cpu is not None:
+                cpu["cpu_model"] = cpu_model_name()
         except Exception as e:  # noqa: BLE001
             log(f"[bench] cpu_baseline failed: {e}")
 
@@ -276,9 +365,13 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone DEM (DATA/DEM/DEM_Ravone.flt), 14 soil layers to 0.95 m"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + f", forcing {args.forcing}, "
-                               f"{args.steps} simulated hours from the initial state",
+                               f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)",
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},
+        "repeats_s": rep_elapsed,
+        "headline_6h": ({"value": 6.0 / elapsed_6h, "unit": "sim-h/s", "hours": "timed hours 0-5 (SURVEY.md 8d headline workload)",
+                         "elapsed_s": elapsed_6h} if args.steps >= 6 and elapsed_6h > 0 else None),
+        "inclusive_value": args.steps / elapsed_incl if elapsed_incl > 0 else None,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -333,7 +333,7 @@ sf3d_error_t sf3d_set_node(uint32_t i, double x, double y, double z, double v, i
     M.x[i] = x; M.y[i] = y; M.z[i] = z; M.size[i] = v;
     M.surf[i] = isSurf != 0;
     sf3d_set_node_boundary(i, bt, slope, barea);
-    if (M.water) { M.pond[i] = isSurf ? 0.0001f : SF3D_NODATA; M.sink[i] = 0.; M.pondDirty = M.sinkDirty = true; }
+    if (M.water) { M.pond[i] = isSurf ? 0.0001f : SF3D_NODATA; M.sink[i] = 0.; M.pondDirty = M.sinkDirty = true; M.sinkLo = 0; M.sinkHi = UINT32_MAX; }
     if (M.heat && !isSurf) {                                        /* :620-626: soil nodes start at 20 degrees C */
         needHeatState();
         M.temperature[i] = 273.15 + 20; M.heatSink[i] = 0.;
@@ -430,7 +430,13 @@ static sf3d_error_t setH(uint32_t i, double H)                      /* soilFluxe
 sf3d_error_t sf3d_set_node_matric_potential(uint32_t i, double psi) { NEED_INIT_E; NEED_NODE_E(i); return setH(i, M.z[i] + psi); }
 sf3d_error_t sf3d_set_node_total_potential(uint32_t i, double H) { NEED_INIT_E; NEED_NODE_E(i); return setH(i, H); }
 sf3d_error_t sf3d_set_node_water_sink_source(uint32_t i, double q)  /* soilFluxes3D.cpp:934-945 */
-{ NEED_INIT_E; NEED_NODE_E(i); M.sink[i] = q; M.sinkDirty = true; return SF3D_OK; }
+{
+    NEED_INIT_E; NEED_NODE_E(i);
+    M.sink[i] = q;
+    if (!M.sinkDirty) { M.sinkLo = i; M.sinkHi = i + 1; M.sinkDirty = true; }
+    else { if (i < M.sinkLo) M.sinkLo = i; if (i + 1 > M.sinkHi) M.sinkHi = i + 1; }
+    return SF3D_OK;
+}
 sf3d_error_t sf3d_set_node_prescribed_total_potential(uint32_t i, double v)   /* soilFluxes3D.cpp:913-927 */
 {
     NEED_INIT_E; NEED_NODE_E(i);

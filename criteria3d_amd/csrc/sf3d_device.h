@@ -10,7 +10,7 @@
  *                  bslope, bsize, prescribed; per (64-node chunk, slot) descriptors ckind/cdelta
  *                  that replace lto/lkind reads wherever the numbering is locally regular
  *   soil classes   SoilDev[] (gathered by cls, L2/scalar-cache resident)
- *   state          X[4][N]: pool of head buffers; H, Hold and Hbest are INDICES into the
+ *   state          X[5][N]: pool of head buffers; H, Hold and Hbest are INDICES into the
  *                  pool kept in Ctrl (no copies on step begin / reject / keep-best / restore)
  *                  Se, K, C, flow, sink, bflowRate, bflowSum, lflowSum[10][N]
  *   linear system  A2[5][N] row-normalised off-diagonals (static ELL, zeros kept; slots paired so
@@ -27,7 +27,7 @@
 #include <stdint.h>
 
 #define SF3D_SLOTS 10
-#define SF3D_POOL 4
+#define SF3D_POOL 5              /* H, Hold, Hbest + two free buffers: the paired sweep writes x' and x'' in one pass */
 #define SF3D_BLOCK 256
 #define SF3D_CHUNK 64            /* one wave64 = 64 consecutive nodes */
 #define SF3D_MAX_BLOCKS 2048     /* 8 blocks of 256 threads per CU x 256 CUs */
@@ -127,6 +127,7 @@ struct Ctrl {
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
     /* ---- quirk-1 compat (SF3D_COMPAT_STALE_LINK_FLOW=1): which assembly k_compat_rows has to mirror into the emulated row storage ---- */
+    uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */
     uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
     uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */
     uint32_t compatSeq;       /* last assembly mirrored                                                            */
@@ -197,6 +198,22 @@ struct HeatDev {
     double* lflux[SF3D_FLUX_TYPES];                 /* [10][N] each; allocated per heatFluxSaveMode_t */
 };
 
+/* ---- paired Jacobi sweep (k_sweep_pair): regular NX x NY x NZ grids in layer-major numbering, one GPU -------------------
+ * Per node a 40-bit code, one nibble per link slot: 0..8 = lateral neighbour (dr + 1) * 3 + (dc + 1) of the same layer,
+ * 9 = the node above (i - NX NY), 10 = the node below, 15 = no link.  Nodes on the grid's edge fill their lateral slots in
+ * their own order (setNodeLink puts the k-th lateral into slot 2 + k), hence a code per node; chunkCode[q] carries the code of
+ * chunk q with bit 63 set when all 64 nodes share it (interior), so that the kernel decodes it on the scalar unit. */
+#define SF3D_PAIR_NONE 15u
+#define SF3D_PAIR_UP 9u
+#define SF3D_PAIR_DOWN 10u
+struct PairGrid {
+    uint32_t NX, NY, NZ;                /* 0 when the graph is not such a grid (k_sweep then) */
+    uint32_t W;                         /* rows of a block's patch (W - 2 owned rows + one halo row on either side) */
+    uint32_t patchCols, patchRows;      /* NX / 64, ceil(NY / (W - 2)) */
+    const uint64_t* nodeCode;           /* [N] */
+    const uint64_t* chunkCode;          /* [N / 64] */
+};
+
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
     uint32_t nChunks;                   /* ceil(N / 64): one wave processes one chunk at a time */
@@ -240,11 +257,12 @@ struct DevView {
     unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
     const SoilDev* soils;
     const double* roughness;
+    PairGrid pair;
     Ctrl* ctrl;
     HeatDev heat;
 };
 
 /* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */
-enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_COUNT };
+enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_COUNT };
 
 #endif

@@ -61,6 +61,8 @@ struct HostModel {
     bool stateDirty = true;      /* H (and Se, K) set through the API                             */
     bool sinkDirty = true, pondDirty = true, boundaryDirty = true, flowSumsDirty = true;
     bool ctrlDirty = true;       /* parameters or balances edited on the host                     */
+    uint32_t sinkLo = 0, sinkHi = UINT32_MAX;   /* node range [lo, hi) touched since the last sink upload (hourly sinks usually cover the
+                                                  * surface nodes only: 2 MB instead of 42 MB at 512 x 512 x 20) */
     /* what the host lacks (device is newer) */
     bool hostStaleState = false; /* H, Se, K                                                      */
     bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */

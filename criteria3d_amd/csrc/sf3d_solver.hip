@@ -137,6 +137,16 @@ __device__ __forceinline__ int free_buffer(const Ctrl* c)
     return 0;   /* unreachable: at most three of four buffers are in use */
 }
 
+/* the two free buffers of the pool of five (paired sweep: x' and x'') */
+__device__ __forceinline__ void free_buffers2(const Ctrl* c, int& f1, int& f2)
+{
+    uint32_t used = (1u << c->cur) | (1u << c->hold);
+    if (c->best >= 0) used |= 1u << c->best;
+    uint32_t fr = ~used & ((1u << SF3D_POOL) - 1u);      /* at least two bits: three of five buffers are in use at most */
+    f1 = __builtin_ctz(fr); fr &= fr - 1u;
+    f2 = __builtin_ctz(fr);
+}
+
 /* fixed-shape block reductions (256 threads = 4 waves of 64) */
 __device__ __forceinline__ double block_sum(double v)
 {
@@ -1329,6 +1339,189 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     if (threadIdx.x == 0) sweep_decision(v.ctrl, nxt, vals[0] / v.N);
 }
 
+/* ---- two Jacobi iterations per pass over the coefficient stream (regular grids, one GPU) -------------------------------------
+ * JacobiWaterCPU (water.cpp:565-601) twice, driven like two calls of solveLinearSystem's loop body (cpusolver.cpp:672-703).
+ * A block owns a patch of W - 2 rows x 64 columns of the horizontal grid and marches down the layers.  Step t:
+ *   stage A  every wave computes x' of layer t for its row of the patch - the patch rows plus one halo row above and below
+ *            (waves 0 .. W-1) and the two halo columns (wave W, one lane per halo cell) - from the old iterate in HBM, exactly
+ *            like k_sweep, and puts it into an LDS ring of four layers; owned cells also store x' and add to the first norm;
+ *   stage B  the owned cells compute x'' of layer t - 1 from the ring (layers t - 2, t - 1, t), with the row's coefficients,
+ *            right-hand side and z kept in registers from step t - 1, store it and add to the second norm.
+ * The 80 B/node of coefficients - 70 % of a sweep's compulsory stream - are read once for two iterations (x 1.25 for the
+ * halo rows at W = 10).  x' and x'' are bit-identical to two k_sweep launches: same operands, same order; the norms are
+ * the same terms summed over another block layout.  Four ring layers make ONE barrier per layer step sufficient: stage A of
+ * step t + 1 writes slot (t + 1) & 3, which no stage B of step t (slots t - 2, t - 1, t) reads.
+ * The block that arrives last takes BOTH convergence decisions in order: if the first iteration already ends the loop, H = x'
+ * (stored for that purpose) and x'' is ignored - the step count and every later decision are those of single sweeps. */
+/* element idx of a device array with a 32-bit BYTE offset (one VGPR next to a scalar base instead of a 64-bit address pair per access;
+ * valid below 2^32 bytes per array - the host enables the paired sweep only for N < 2^28) */
+template <class T> __device__ __forceinline__ const T* at32(const T* base, uint32_t idx)
+{
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (idx * (uint32_t)sizeof(T)));
+}
+template <class T> __device__ __forceinline__ T* at32(T* base, uint32_t idx)
+{
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (idx * (uint32_t)sizeof(T)));
+}
+__device__ __forceinline__ uint32_t pair_nib(uint64_t code, int s) { return (s < 8 ? (uint32_t)code >> (4 * s) : (uint32_t)(code >> 32) >> (4 * (s - 8))) & 15u; }
+/* index offset of the neighbour a nibble names */
+__device__ __forceinline__ int32_t pair_goff(uint32_t n, int32_t NX, int32_t layer)
+{
+    const int32_t t = (int32_t)((n * 11u) >> 5);                       /* n / 3 for n = 0..8 */
+    const int32_t lat = (t - 1) * NX + ((int32_t)n - 3 * t - 1);
+    return n < 9u ? lat : (n == SF3D_PAIR_UP ? -layer : (n == SF3D_PAIR_DOWN ? layer : 0));
+}
+/* position in the ring relative to the cell's own position in layer l (l & 3 = k), in doubles */
+template <int W>
+__device__ __forceinline__ int32_t pair_loff(uint32_t n, int32_t k)
+{
+    const int32_t t = (int32_t)((n * 11u) >> 5);
+    const int32_t lat = (t - 1) * 66 + ((int32_t)n - 3 * t - 1);
+    const int32_t up = (((k + 3) & 3) - k) * (W * 66), down = (((k + 1) & 3) - k) * (W * 66);
+    return n < 9u ? lat : (n == SF3D_PAIR_UP ? up : (n == SF3D_PAIR_DOWN ? down : 0));
+}
+
+#ifndef SF3D_PAIR_WAVES
+#define SF3D_PAIR_WAVES 6      /* waves per SIMD the register budget is cut for: two blocks of eleven waves per CU at W = 10 */
+#endif
+/* Registers: the coefficients of layer t - 1 are needed again only after the barrier of step t, by which time the loads of
+ * layer t (five 16-byte coefficient loads, b, z, x and ten gathers per lane, all in flight at once) have come and gone: in
+ * between they are parked in LDS (thread-private slots, 96 B per owned cell: 49 KB per block at W = 10 next to the 21 KB ring;
+ * two blocks per CU use 140 of the 160 KB).  The nibbles of a code are turned into offsets through two small LDS tables
+ * (one ds_read per slot instead of a dozen integer instructions per lane). */
+template <int W, bool NT>
+__global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP) return;
+    __shared__ double ring[4][W][66];
+    __shared__ sf3d_d2 parked[SF3D_SLOTS / 2 + 1][W - 2][64];      /* five coefficient pairs + (b, z) */
+    __shared__ int32_t tabG[16], tabL[4][16];
+    __shared__ double sm[2][W + 1];
+    int nxt1, nxt2;
+    free_buffers2(c, nxt1, nxt2);
+    const double* __restrict__ xin = v.X[c->cur];
+    double* __restrict__ xo1 = v.X[nxt1];
+    double* __restrict__ xo2 = v.X[nxt2];
+    const int32_t NX = (int32_t)v.pair.NX, NY = (int32_t)v.pair.NY, NZ = (int32_t)v.pair.NZ;
+    const int32_t layer = NX * NY;
+    if (threadIdx.x < 16) tabG[threadIdx.x] = pair_goff(threadIdx.x, NX, layer);
+    if (threadIdx.x < 64) tabL[threadIdx.x >> 4][threadIdx.x & 15] = pair_loff<W>(threadIdx.x & 15, threadIdx.x >> 4);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pr = blockIdx.x / v.pair.patchCols, pc = blockIdx.x % v.pair.patchCols;
+    int r0 = pr * (W - 2) - 1;
+    if (r0 + W > NY + 1) r0 = NY + 1 - W;          /* the last patch of a column of patches is shifted up instead of hanging over the edge */
+    const int c0 = pc * 64;
+    const bool halo = wave == W;
+    const int prow = halo ? (lane >> 1) : wave;
+    const int r = r0 + prow;
+    const int col = halo ? ((lane & 1) ? c0 + 64 : c0 - 1) : c0 + lane;
+    const int slot = halo ? ((lane & 1) ? 65 : 0) : lane + 1;
+    const bool ok = prow < W && r >= 0 && r < NY && col >= 0 && col < NX;
+    /* every cell is owned by exactly one block; owned rows sit in waves 1 .. W - 2 */
+    const bool owned = !halo && ok && wave >= 1 && wave <= W - 2 && r >= pr * (W - 2) && r < (pr + 1) * (W - 2);
+    const uint32_t i0 = ok ? (uint32_t)(r * NX + col) : 0u;
+    const bool rowWave = !halo && r >= 0 && r < NY;        /* wave-uniform: this wave's 64 cells are chunk (t layer + i0) / 64 */
+    double n1 = 0., n2 = 0.;
+    const int32_t ownPos = (wave < W ? wave : 0) * 66 + lane + 1;      /* own position inside one ring layer (row waves) */
+    sf3d_d2* park = &parked[0][(wave >= 1 && wave <= W - 2) ? wave - 1 : 0][lane];
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    constexpr size_t PSTRIDE = (size_t)(W - 2) * 64;
+    __syncthreads();
+    for (int t = 0; t <= NZ; ++t) {
+        double ac[SF3D_SLOTS], bc = 0., zc = 0.;
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) ac[s] = 0.;
+        if (t < NZ && prow < W) {                              /* stage A: x' of layer t */
+            double x1 = 0.;
+            if (ok) {
+                const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
+                uint64_t code = 0;
+                if (rowWave) code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];      /* scalar load */
+                if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
+                double xj[SF3D_SLOTS];
+                #pragma unroll
+                for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(v.A2 + (size_t)p * v.N, i)); ac[2 * p] = w.x; ac[2 * p + 1] = w.y; }
+                bc = *at32(v.b, i); zc = *at32(v.z, i);
+                const double xi = *at32(xin, i);
+                #pragma unroll
+                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = *at32(xin, (uint32_t)((int32_t)i + tabG[pair_nib(code, s)]));
+                x1 = bc;
+                #pragma unroll
+                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ac[s] != 0.) x1 -= ac[s] * xj[s]; }
+                if (t == 0) x1 = dmax(x1, zc);
+                if (owned) {
+                    double d = fabs(x1 - xi);
+                    const double psi = fabs(x1 - zc);
+                    if (psi > 1.) d *= (1. / psi);
+                    n1 += d;
+                    *at32(xo1, i) = x1;
+                }
+            }
+            ring[t & 3][prow][slot] = x1;
+        }
+        __syncthreads();
+        if (owned) {
+            /* this layer's row goes to its LDS parking place (thread-private slots: no barrier needed) and the previous layer's
+             * comes back from it, pair by pair, so that the two rows are never in registers at the same time */
+            double ap[SF3D_SLOTS];
+            #pragma unroll
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
+                const sf3d_d2 w = park[(size_t)p * PSTRIDE];
+                sf3d_d2 n; n.x = ac[2 * p]; n.y = ac[2 * p + 1];
+                park[(size_t)p * PSTRIDE] = n;
+                ap[2 * p] = w.x; ap[2 * p + 1] = w.y;
+            }
+            const sf3d_d2 bz = park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE];
+            { sf3d_d2 n; n.x = bc; n.y = zc; park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE] = n; }
+            if (t >= 1) {                                      /* stage B: x'' of layer t - 1 from the ring */
+                const int l = t - 1;
+                const uint32_t i = (uint32_t)l * (uint32_t)layer + i0;
+                const double* own = &ring[l & 3][0][0] + ownPos;
+                uint64_t code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];          /* owned cells sit in row waves */
+                if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
+                double xj[SF3D_SLOTS];
+                const int32_t* tl = tabL[l & 3];
+                #pragma unroll
+                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = own[tl[pair_nib(code, s)]];
+                const double x1 = own[0];
+                double x2 = bz.x;
+                #pragma unroll
+                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ap[s] != 0.) x2 -= ap[s] * xj[s]; }
+                if (l == 0) x2 = dmax(x2, bz.y);
+                double d = fabs(x2 - x1);
+                const double psi = fabs(x2 - bz.y);
+                if (psi > 1.) d *= (1. / psi);
+                n2 += d;
+                *at32(xo2, i) = x2;
+            }
+        }
+    }
+    /* both norms: waves in order inside the block, blocks in index order by the block that arrives last */
+    for (int off = 32; off > 0; off >>= 1) { n1 += __shfl_down(n1, off, 64); n2 += __shfl_down(n2, off, 64); }
+    if (lane == 0) { sm[0][wave] = n1; sm[1][wave] = n2; }
+    __syncthreads();
+    double s1 = 0., s2 = 0.;
+    if (threadIdx.x == 0) for (int w = 0; w <= W; ++w) { s1 += sm[0][w]; s2 += sm[1][w]; }
+    if (!arrive_last(v, s1, s2, true)) return;
+    double t1 = 0., t2 = 0.;
+    if (threadIdx.x < SF3D_BLOCK)
+        for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK) {
+            t1 += __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += __hip_atomic_load(&v.part1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64); }
+    __syncthreads();
+    if (lane == 0) { sm[0][wave] = t1; sm[1][wave] = t2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), b = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+        c->pairLaunches++;
+        sweep_decision(c, nxt1, a / v.N);                               /* first iteration: H candidate = x' */
+        if (c->stage == ST_SWEEP) sweep_decision(c, nxt2, b / v.N);     /* the loop goes on: second iteration, x'' */
+    }
+}
+
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
                                               double Se, double& st, double& sk)
 {
@@ -1532,7 +1725,7 @@ template <class F> void parallel_for(uint32_t n, F f)
     for (auto& t : th) t.join();
 }
 
-const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept"};
+const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept", "k_sweep_pair"};
 
 }  // namespace
 
@@ -1626,6 +1819,7 @@ struct DeviceSolver::Impl {
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
     int fuseFirstSweep = -1;              /* SF3D_FUSE_FIRST_SWEEP=1: k_assemble also does the first Jacobi iteration (measured slower) */
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
+    uint32_t pairBlocks = 0;              /* grid of k_sweep_pair (0: the graph is no regular grid, or the paired sweep is off) */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -1826,6 +2020,68 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             }
         });
 
+        /* paired sweep (k_sweep_pair): is the graph a regular NX x NY x NZ grid in layer-major numbering, and which neighbour
+         * does every link slot of every node name?  (host logic; the same structure sf3d_get_regular_grid reports) */
+        std::vector<uint64_t> pairNode, pairChunk;
+        uint32_t pairNX = 0, pairNY = 0, pairNZ = 0;
+        {
+            const char* pe = getenv("SF3D_PAIR_SWEEP");
+            const int want = pe ? (pe[0] == '0' ? 0 : 1) : -1;          /* -1: automatic (large grids only, decided below) */
+            bool regular = world_ == 1 && want != 0 && ns >= 64 && N % ns == 0 && N / ns >= 2 && N < (1u << 28);   /* 32-bit byte offsets in the kernel */
+            int64_t maxOff = 0;
+            if (regular) {
+                for (int sl = 2; sl < SF3D_SLOTS && regular; ++sl)
+                    for (uint32_t i = 0; i < N; ++i) {
+                        const size_t e = (size_t)sl * N + i;
+                        if (kind[e] == LK_NONE) continue;
+                        const int64_t o = std::llabs((int64_t)to[e] - (int64_t)i);
+                        if (o > maxOff) maxOff = o;
+                    }
+                const int64_t NX = maxOff - 1;
+                regular = NX >= 64 && NX % 64 == 0 && ns % (uint64_t)NX == 0 && ns / (uint64_t)NX >= 6;
+                if (regular) { pairNX = (uint32_t)NX; pairNY = (uint32_t)(ns / (uint64_t)NX); pairNZ = N / ns; }
+            }
+            if (regular) {
+                pairNode.assign(N, 0);
+                std::atomic<bool> irregular{false};
+                const int64_t NX = pairNX, NY = pairNY;
+                parallel_for(N, [&](uint32_t a, uint32_t b) {
+                    for (uint32_t i = a; i < b && !irregular.load(std::memory_order_relaxed); ++i) {
+                        const int64_t l = i / ns, r = (i % ns) / NX, cidx = i % NX;
+                        uint64_t code = 0; unsigned seen = 0;
+                        for (int sl = 0; sl < SF3D_SLOTS; ++sl) {
+                            const size_t e = (size_t)sl * N + i;
+                            uint64_t nib = SF3D_PAIR_NONE;
+                            if (kind[e] != LK_NONE) {
+                                const int64_t off = (int64_t)to[e] - (int64_t)i;
+                                if (sl == 0) { if (off != -(int64_t)ns) irregular = true; nib = SF3D_PAIR_UP; }
+                                else if (sl == 1) { if (off != (int64_t)ns) irregular = true; nib = SF3D_PAIR_DOWN; }
+                                else {
+                                    const int64_t rr = (off >= 0) ? (off + NX / 2) / NX : -((-off + NX / 2) / NX), cc = off - rr * NX;
+                                    if (rr < -1 || rr > 1 || cc < -1 || cc > 1 || (rr == 0 && cc == 0) || r + rr < 0 || r + rr >= NY || cidx + cc < 0 || cidx + cc >= NX
+                                        || (int64_t)(to[e] / ns) != l) { irregular = true; break; }
+                                    nib = (uint64_t)((rr + 1) * 3 + (cc + 1));
+                                    if (seen & (1u << nib)) irregular = true;      /* two links to one neighbour */
+                                    seen |= 1u << nib;
+                                }
+                            }
+                            code |= nib << (4 * sl);
+                        }
+                        pairNode[i] = code;
+                    }
+                });
+                regular = !irregular;
+            }
+            if (regular) {
+                pairChunk.assign(nChunks, 0);
+                for (uint32_t q = 0; q < nChunks; ++q) {
+                    bool same = (size_t)(q + 1) * SF3D_CHUNK <= N;
+                    for (uint32_t k = 1; k < SF3D_CHUNK && same; ++k) same = pairNode[(size_t)q * SF3D_CHUNK + k] == pairNode[(size_t)q * SF3D_CHUNK];
+                    if (same) pairChunk[q] = pairNode[(size_t)q * SF3D_CHUNK] | (1ull << 63);
+                }
+            } else { pairNode.clear(); pairNX = pairNY = pairNZ = 0; }
+        }
+
         /* ownership + chunk lists (identity lists on one GPU) */
         {
             sf3d_error_t pe = sf3d_compute_partition(m, rank_, world_, I.part);
@@ -1913,6 +2169,36 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             const char* e = getenv("SF3D_NT_STREAM");
             const double sweepBytes = 152.0 * (double)v.nList * SF3D_CHUNK;
             v.ntStream = e ? (e[0] != '0') : (sweepBytes > 256.0 * 1024 * 1024);
+        }
+        I.pairBlocks = 0;
+        if (!pairNode.empty()) {
+            /* the paired sweep pays where the sweep streams from HBM (ntStream: above the Infinity Cache) - below that the plain sweep
+             * is cache-resident and faster; SF3D_PAIR_SWEEP=1 forces it on any regular grid (tests on small grids) */
+            const char* pe = getenv("SF3D_PAIR_SWEEP");
+            const bool on = pe ? (pe[0] != '0') : (v.ntStream != 0);
+            if (on) {
+                int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, I.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
+                uint32_t bestW = 0; double bestCost = 1e30;
+                const char* we = getenv("SF3D_PAIR_W");
+                for (uint32_t W : {6u, 10u, 14u}) {
+                    if (pairNY < W || (we && (uint32_t)atoi(we) != W)) continue;
+                    const uint64_t blocks = (uint64_t)((pairNY + W - 3) / (W - 2)) * (pairNX / 64);
+                    const uint64_t resident = (uint64_t)(4 * SF3D_PAIR_WAVES / (W + 1)) * cus;     /* blocks of W + 1 waves per CU */
+                    const uint64_t rounds = (blocks + resident - 1) / resident;
+                    const double cost = (double)(rounds * resident) / (double)blocks * (double)W / (double)(W - 2);
+                    if (cost < bestCost) { bestCost = cost; bestW = W; }
+                }
+                if (bestW) {
+                    uint64_t *dn, *dq;
+                    HIP_TRY(dev_alloc(I.allocs, dn, pairNode.size())); HIP_TRY(dev_alloc(I.allocs, dq, pairChunk.size()));
+                    HIP_TRY(hipMemcpy(dn, pairNode.data(), pairNode.size() * 8, hipMemcpyHostToDevice));
+                    HIP_TRY(hipMemcpy(dq, pairChunk.data(), pairChunk.size() * 8, hipMemcpyHostToDevice));
+                    v.pair.NX = pairNX; v.pair.NY = pairNY; v.pair.NZ = pairNZ; v.pair.W = bestW;
+                    v.pair.patchCols = pairNX / 64; v.pair.patchRows = (pairNY + bestW - 3) / (bestW - 2);
+                    v.pair.nodeCode = dn; v.pair.chunkCode = dq;
+                    I.pairBlocks = v.pair.patchCols * v.pair.patchRows;
+                }
+            }
         }
         if (world_ > 1) {
             uint8_t* downer; HIP_TRY(dev_alloc(I.allocs, downer, N));
@@ -2003,7 +2289,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
-        HIP_TRY(dev_alloc(I.allocs, v.part0, v.nb + v.nbSurf + 8)); HIP_TRY(dev_alloc(I.allocs, v.part1, v.nb + v.nbSurf + 8));
+        {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, I.pairBlocks) + 8;
+            HIP_TRY(dev_alloc(I.allocs, v.part0, np)); HIP_TRY(dev_alloc(I.allocs, v.part1, np)); }
         HIP_TRY(dev_alloc(I.allocs, v.arrive, 16 * 17)); HIP_TRY(hipMemset(v.arrive, 0, 16 * 17 * sizeof(unsigned int)));
         HIP_TRY(dev_alloc(I.allocs, soils, m.soils.size())); HIP_TRY(dev_alloc(I.allocs, roughness, m.roughness.size()));
         HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
@@ -2121,6 +2408,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         built_ = true;
         m.graphDirty = false;
         m.stateDirty = m.sinkDirty = m.pondDirty = m.boundaryDirty = m.flowSumsDirty = m.ctrlDirty = true;
+        m.sinkLo = 0; m.sinkHi = UINT32_MAX;
         m.hostStaleState = m.hostStaleFlows = false;
     }
 
@@ -2132,7 +2420,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         mirror_.seSource = 0; m.ctrlDirty = true;      /* Se now comes from the host's libm: the next attempt recomputes it on the device */
         m.stateDirty = false;
     }
-    if (m.sinkDirty) { HIP_TRY(hipMemcpyAsync((void*)v.sink, m.sink.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.sinkDirty = false; }
+    if (m.sinkDirty) {
+        const uint32_t lo = m.sinkLo < N ? m.sinkLo : 0u, hi = m.sinkHi > N ? N : m.sinkHi;      /* only the range the setters touched */
+        if (hi > lo) HIP_TRY(hipMemcpyAsync((void*)(v.sink + lo), m.sink.data() + lo, (size_t)(hi - lo) * 8, hipMemcpyHostToDevice, I.stream));
+        m.sinkDirty = false; m.sinkLo = 0; m.sinkHi = 0;
+    }
     if (m.pondDirty) { HIP_TRY(hipMemcpyAsync((void*)v.pond, m.pond.data(), N * 8, hipMemcpyHostToDevice, I.stream)); m.pondDirty = false; }
     if (m.boundaryDirty) {
         HIP_TRY(hipMemcpyAsync((void*)v.btype, m.btype.data(), N, hipMemcpyHostToDevice, I.stream));
@@ -2431,6 +2723,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (heatOn && multi) I.useFused = 1;       /* the sharded heat step exists only in the fused-exchange form */
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
+    const bool pairOn = fused && I.pairBlocks != 0 && !fuse0;   /* k_sweep_pair instead of k_sweep */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
@@ -2445,7 +2738,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
      * per-kernel event timing of --time-all-kernels stays a sequence of exclusive launches) */
     const bool overlap = I.overlapAccept && !multi && I.stream2 && !timedStep && I.timing != 1;
     auto timed = [&](int kid, auto launch) {
-        if (!timedStep || (I.timing == 2 && kid != KID_SWEEP)) { launch(); return; }
+        if (!timedStep || (I.timing == 2 && kid != KID_SWEEP && kid != KID_SWEEP_PAIR)) { launch(); return; }
         hipEvent_t a, b;
         if (I.freeEvents.size() >= 2) { a = I.freeEvents.back(); I.freeEvents.pop_back(); b = I.freeEvents.back(); I.freeEvents.pop_back(); }
         else { hipEventCreate(&a); hipEventCreate(&b); }
@@ -2466,6 +2759,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     std::memcpy(before, mirror_.counters, sizeof(before));
     std::memcpy(atStart, mirror_.counters, sizeof(atStart));
     int guard = 0;
+    uint64_t pairBefore = mirror_.pairLaunches;
 
     const dim3 propsGrid = resident((const void*)k_props<0, false>), propsHeatGrid = resident((const void*)k_props<0, true>);
     const dim3 acceptGrid = v.ntStream ? resident((const void*)k_accept<true>) : resident((const void*)k_accept<false>);
@@ -2500,6 +2794,20 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
+        if (pairOn) {      /* two Jacobi iterations per launch (regular grid, one GPU): ceil(chunk / 2) launches */
+            const dim3 pgr(I.pairBlocks), pbl((v.pair.W + 1) * 64);
+            for (uint32_t k = 0; k < (chunk + 1) / 2; ++k)
+                timed(KID_SWEEP_PAIR, [&] {
+                    switch (v.pair.W * 2 + (v.ntStream ? 1 : 0)) {
+                        case 12: hipLaunchKernelGGL((k_sweep_pair<6, false>), pgr, pbl, 0, st, v); break;
+                        case 13: hipLaunchKernelGGL((k_sweep_pair<6, true>), pgr, pbl, 0, st, v); break;
+                        case 20: hipLaunchKernelGGL((k_sweep_pair<10, false>), pgr, pbl, 0, st, v); break;
+                        case 21: hipLaunchKernelGGL((k_sweep_pair<10, true>), pgr, pbl, 0, st, v); break;
+                        case 28: hipLaunchKernelGGL((k_sweep_pair<14, false>), pgr, pbl, 0, st, v); break;
+                        default: hipLaunchKernelGGL((k_sweep_pair<14, true>), pgr, pbl, 0, st, v); break;
+                    }
+                });
+        } else
         for (uint32_t k = 0; k < chunk; ++k) {
             if (fused) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<1, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<1, false>), grid, block, 0, st, v); }); continue; }
             if (fusedMulti) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<2, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<2, false>), grid, block, 0, st, v); }); continue; }
@@ -2535,7 +2843,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
         if (chunk < 4) chunk = 4;
         if (chunk > 40) chunk = 40;
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -2576,7 +2884,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
              * comes from the device counters; guarded no-op launches are the shortest of a group */
             uint64_t ran[KID_COUNT];
             ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
-            ran[KID_SWEEP] = c.counters[3] - before[3];
+            ran[KID_SWEEP] = pairOn ? 0 : c.counters[3] - before[3];
+            ran[KID_SWEEP_PAIR] = c.pairLaunches - pairBefore;
             if (fuse0) ran[KID_SWEEP] -= (c.counters[2] - before[2]) - (c.counters[4] - before[4]);   /* first iterations: inside k_assemble */
             ran[KID_POST] = c.counters[7] - before[7];
             ran[KID_RESTORE] = c.counters[6] - before[6];
@@ -2594,6 +2903,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
         }
         std::memcpy(before, c.counters, sizeof(before));
+        pairBefore = c.pairLaunches;
 
         stage = c.stage;
         if (stage != ST_SWEEP && c.iter > 0) I.lastSweeps = c.iter;

@@ -10,6 +10,26 @@ from criteria3d_amd import capi, catchment as cm
 SCALARS = ("total_water", "storage", "mbr", "runoff", "drainage", "lateral")
 
 
+class env:
+    """`with env(SF3D_X=1): ...` - the libraries read their SF3D_* switches when a model is built (sf3d_initialize / the first
+    computeStep after it), so a test can run one scenario per mode in one process"""
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        import os
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+
+    def __exit__(self, *a):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def _hours(sf, m, plan, threads=1, use_period=False, wrc=None, mean=None, sinks_fn=None, pre=None):
     """plan: list of (rain_mm, max_steps or None, keep_arrays)"""
     sf.lib.sf3d_reset_solver_state()

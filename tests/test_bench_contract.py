@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_has_every_contract_field():
-    files = sorted(glob.glob(str(ROOT / "profiles" / "r01_?_bench.json")))
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r0?_?_bench.json")))
     assert files, "no committed bench line under profiles/"
     line = json.load(open(files[-1]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -69,10 +69,45 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert line["config"]["work"]["accepted"] == 22
 
 
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher - how the driver calls it - starts two fresh rank processes itself, relays rank
+    0's line and carries the self-describing fields (driver-timed 6-hour headline, repetitions, inclusive rate, traffic source)"""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SF3D_BENCH_SHARE_GPU"] = "1"
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "6", "--warmup", "0", "--reps", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
+    assert len(line["repeats_s"]) == 2 and min(line["repeats_s"]) > 0
+    assert line["headline_6h"]["value"] > 0 and abs(line["headline_6h"]["value"] - line["value"]) < 0.35 * line["value"]
+    assert 0 < line["inclusive_value"] <= line["value"] * 1.02
+    assert line["config"]["work"]["accepted"] == 50          # C2 F20: 22 + 13 + 6 + 3 + 3 + 3 (SURVEY.md 8c)
+    assert "traffic_source" in line["roofline"]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """--gpus must equal the launcher's WORLD_SIZE; the message says what to do (runs without a GPU: the check comes first)"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
 def test_bench_reads_an_existing_pmc_summary():
     """roofline.traffic comes from the committed rocprofv3 PMC summary bench.py names: the file must exist and carry the dominant kernel"""
     import re
     src = (ROOT / "bench.py").read_text()
-    name = re.search(r'"profiles" / "(r01_\w+_kernel_summary\.json)"', src).group(1)
+    tags = re.search(r'for tag in \(([^)]*)\)', src).group(1)
+    names = [f"{t.strip().strip(chr(34))}_kernel_summary.json" for t in tags.split(",")]
+    name = next(n for n in names if (ROOT / "profiles" / n).exists())
     prof = json.load(open(ROOT / "profiles" / name))
     assert prof["k_sweep"]["hbm_traffic_MB"] > 0.5 * 152 * 5242880 / 1e6

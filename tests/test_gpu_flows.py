@@ -14,21 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 RTOL = 1e-6
 
 
-class env:
-    """SF3D_* switches are read when a model is built (sf3d_initialize / first computeStep after it)"""
-    def __init__(self, **kw):
-        self.kw = kw
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kw}
-        os.environ.update({k: str(v) for k, v in self.kw.items()})
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+env = sc.env
 
 
 FLOW_RTOL = 1e-5

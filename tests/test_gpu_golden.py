@@ -8,7 +8,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from tests.scenarios import SCENARIOS, HEAT_SCENARIOS, run_scenario
+from tests.scenarios import SCENARIOS, HEAT_SCENARIOS, env, run_scenario
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -43,7 +43,8 @@ def test_product_heat_advection_matches_reference_vectors(product):
     """advective heat flux (initializeHeatFlag(All, true, true)) over eight 2 s steps - the regime in which the reference's
     own advective term is still finite (tests/scenarios.py::heat_advection_steps)"""
     gold = np.load(GOLDEN / "heat_advection_steps.npz")
-    trace = run_scenario(product, "heat_advection_steps", threads=1)
+    with env(SF3D_COMPAT_STALE_LINK_FLOW="1"):           # quirk-1 emulation: no link of the vector has to be left out
+        trace = run_scenario(product, "heat_advection_steps", threads=1)
     np.testing.assert_allclose(trace["dts"], gold["dts"], rtol=1e-12)
     soil = slice(120, None)                                              # the 12 x 10 surface nodes carry no temperature
     assert _close(trace["T"][:, soil], gold["T"][:, soil], 1e-6, 1e-9)
@@ -54,22 +55,22 @@ def test_product_heat_advection_matches_reference_vectors(product):
     assert np.array_equal(a == -9999.0, b == -9999.0)
     for t in range(b.shape[-1]):
         ok = b[..., t] != -9999.0
-        if t == 5:
-            ok &= ~((a[..., t] == 0.0) & (b[..., t] != 0.0))
         if np.any(ok):
             sc = max(np.max(np.abs(b[..., t][ok])), 1e-30)
             assert np.all(np.abs(a[..., t][ok] - b[..., t][ok]) <= 2e-6 * sc), (t, np.max(np.abs(a[..., t][ok] - b[..., t][ok])), sc)
 
 
+@pytest.mark.parametrize("compat", ["0", "1"])
 @pytest.mark.parametrize("name", [k for k in HEAT_SCENARIOS if k != "heat_advection_steps"])
-def test_product_heat_matches_reference_vectors(product, name):
+def test_product_heat_matches_reference_vectors(product, name, compat):
     """Coupled heat transport (heat.cpp) against the reference's vectors: temperature, potential and heat storage
     within 1e-6 relative; boundary fluxes and conductances within 1e-6 of their scale; the link fluxes, which the
     reference rounds through float, within 2e-6 of the largest flux of their type; identical accepted-dt sequences.
     (The reference sweeps the heat system with a serial Gauss-Seidel, the device with Jacobi, both to the
     reference's stopping rule of 1e-10 K.)"""
     gold = np.load(GOLDEN / f"{name}.npz")
-    trace = run_scenario(product, name, threads=1)
+    with env(SF3D_COMPAT_STALE_LINK_FLOW=compat):        # "1": quirk-1 emulation - the saved water fluxes of dropped links are compared too
+        trace = run_scenario(product, name, threads=1)
     assert set(trace) == set(gold.files)
     assert np.array_equal(trace["steps_per_hour"], gold["steps_per_hour"]), (trace["steps_per_hour"], gold["steps_per_hour"])
     np.testing.assert_allclose(trace["dts"], gold["dts"], rtol=1e-12)
@@ -87,7 +88,7 @@ def test_product_heat_matches_reference_vectors(product, name):
             for t in range(b.shape[-1]):
                 bt, at = b[..., t], a[..., t]
                 ok = bt != -9999.0
-                if t == 5:      # WaterLiquidIsothermal: stale-matrix-slot deviation, see tests/test_oracle_golden.py
+                if t == 5 and compat == "0":      # WaterLiquidIsothermal of a dropped link: 0 by default, the reference's stale slot in compat mode
                     ok &= ~((at == 0.0) & (bt != 0.0))
                 if not np.any(ok):
                     continue
