@@ -99,6 +99,41 @@ def build_v2_demo(force: bool = False) -> Path:
     return demo
 
 
+STATIC_LIB = ROOT / "shim" / "libsoilFluxes3D.a"
+QT_INC = Path(os.environ.get("SF3D_QT_INC", "/opt/conda/include/qt"))
+QT_CORE = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))
+
+
+def build_static_dropin(force: bool = False):
+    """INTEGRATION.md section 2, executed: the shim compiled against the application's OWN headers (soilFluxes3D.h, types.h,
+    lineal/linealiaLib.h -> <QLibrary>) with the LinealiaLib stub, archived as libsoilFluxes3D.a - the file name
+    bin/CRITERIA3D/CRITERIA3D.pro:65,93 links - and tests/v2_caller_demo.cpp (plus the LinealiaLib::instance().load() call of
+    main.cpp:81) linked against that archive the way the .pro change says.  Needs the reference headers and Qt: returns None
+    elsewhere (the GPU box runs the prebuilt demo)."""
+    ref_inc = REFERENCE / "agrolib" / "soilFluxes3D"
+    if not (ref_inc / "soilFluxes3D.h").exists() or not (QT_INC / "QtCore").exists() or not QT_CORE.exists():
+        return None
+    src = ROOT / "shim" / "sf3d_cxx_shim.cpp"
+    obj = ROOT / "shim" / "sf3d_cxx_shim_static.o"
+    inc = [f"-I{ref_inc}", f"-I{ref_inc / 'lineal'}", f"-I{REFERENCE / 'agrolib' / 'mathFunctions'}", f"-I{INCLUDE}",
+           f"-I{QT_INC}", f"-I{QT_INC / 'QtCore'}"]
+    if force or _stale(STATIC_LIB, [src, INCLUDE / "sf3d.h"]):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-c", str(src), "-DSF3D_USE_REFERENCE_HEADER", "-DSF3D_WITH_LINEALIA_STUB", *inc, "-o", str(obj)])
+        if STATIC_LIB.exists():
+            STATIC_LIB.unlink()
+        _run(["ar", "rcs", str(STATIC_LIB), str(obj)])
+    demo = ROOT / "shim" / "v2_static_demo"
+    dsrc = ROOT / "tests" / "v2_caller_demo.cpp"
+    build_product()
+    if force or _stale(demo, [dsrc, STATIC_LIB, PRODUCT_LIB]):
+        # the application's link line after the INTEGRATION.md change: -lsoilFluxes3D (the archive) + the HIP library + Qt
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-DSF3D_USE_REFERENCE_HEADER", "-DSF3D_DEMO_LINEALIA", *inc, str(dsrc), "-o", str(demo),
+              f"-L{ROOT / 'shim'}", "-l:libsoilFluxes3D.a", f"-L{CSRC}", "-lsf3d_hip", f"-Wl,-rpath,{CSRC}", str(QT_CORE)])
+        # (no rpath to the image's conda Qt: that directory also holds an older libstdc++ that must not shadow the system one -
+        # tests run the demo with LD_PRELOAD="<system libstdc++> <libQt5Core>", a real deployment has Qt on the loader path)
+    return STATIC_LIB
+
+
 def build_oracle(with_reference: bool = True) -> None:
     """Test infrastructure: the CPU restatement and (when /root/reference is present) oracle/_ref."""
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
@@ -113,4 +148,5 @@ def build_all(force: bool = False) -> None:
     build_shim(force)
     build_v1_alias(force)
     build_v2_demo(force)
+    build_static_dropin(force)
     build_oracle()

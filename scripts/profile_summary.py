@@ -21,7 +21,7 @@ if f:
         dur[base(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     for k, v in dur.items():
         ref = sorted(v)[int(0.9 * (len(v) - 1))]        # 90th percentile: one slow outlier must not hide the real launches
-        active = [x for x in v if x > 0.25 * ref] if k in ("k_sweep", "k_props", "k_assemble", "k_post", "k_accept", "k_restore") else v
+        active = [x for x in v if x > 0.25 * ref] if k in ("k_sweep", "k_sweep_pair", "k_props", "k_assemble", "k_post", "k_accept", "k_accept_links", "k_restore") else v
         res.setdefault(k, {})["launches"] = len(v)
         res[k]["active_launches"] = len(active)
         res[k]["avg_active_us"] = sum(active) / max(len(active), 1) / 1e3

@@ -107,9 +107,13 @@ double computeStep(double t) { return sf3d_compute_step(t); }
 }}  // namespace soilFluxes3D::v2
 
 #ifdef SF3D_WITH_LINEALIA_STUB
-/* bin/CRITERIA3D/main.cpp:81 calls LinealiaLib::instance().load(); the MI355X library always uses
- * its own device Jacobi, so "not loaded" is the truthful answer (the app then runs with
- * useLineal=false, src/project3D/project3D.cpp:53). */
+/* bin/CRITERIA3D/main.cpp:81 calls LinealiaLib::instance().load() (lineal/linealiaLib.h; defined by lineal/linealiaLib.cpp, which
+ * leaves the link line together with the rest of agrolib/soilFluxes3D).  The MI355X library never dlopens the third-party
+ * liblinealia: "not loaded" is the truthful answer, and the application then runs with useLineal = false
+ * (src/project3D/project3D.cpp:53).  Only the members a caller outside the solver can reach are defined. */
 #include "linealiaLib.h"
+LinealiaLib& LinealiaLib::instance() { static LinealiaLib one; return one; }
+LinealiaLib::LinealiaLib() : lib("liblinealia") {}
 bool LinealiaLib::load() { return false; }
+bool LinealiaLib::isLoaded() const { return false; }
 #endif

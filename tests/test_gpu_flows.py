@@ -17,20 +17,22 @@ RTOL = 1e-6
 env = sc.env
 
 
-FLOW_RTOL = 1e-5
+FLOW_RTOL = {"up": 1e-5, "down": 1e-5, "lateral_max": 1e-3, "lateral_sum": 1e-3, "lateral_in": 1e-3, "lateral_out": 1e-3}
 
 
 def flows_close(a, b, what):
-    """A link flow sum accumulates a_ij (H_i - H_j) dt: a difference of two heads of ~100 m that are 0.1-1 m apart, so the 1e-6
-    band of H (measured: 2e-10 ... 6e-8) is a 100-1000 times wider band of the difference.  The sums are therefore held to 1e-5
-    of the largest sum of the same kind in the model (measured: 1.5e-6 on C2 F20 Up, below 1e-6 elsewhere); the boundary sums,
-    which are balance terms, keep the 1e-6 of the north star."""
+    """A link flow sum accumulates a_ij (H_i - H_j) dt.  Vertical links: a difference of two heads of ~100 m that are 0.1-1 m
+    apart, so the 1e-6 band of H (measured: 2e-10 ... 6e-8) is a 100-1000 times wider band of the difference - held to 1e-5 of the
+    largest sum of the same kind in the model (measured: 1.5e-6 on C2 F20 Up).  Lateral links are dominated by the surface
+    (runoff) links, whose conductance goes with Hs^(5/3), Hs = max(H) - max(z + pond) being MILLIMETRES of water computed from
+    those 100 m heads (water.cpp:413-487): 1e-8 of H is 1e-3 of Hs - held to 1e-3 of the largest sum of the kind (measured: 1.3e-4).
+    The boundary sums, which are balance terms, keep the 1e-6 of the north star."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape
     for k, name in enumerate(cm.LINK_FLOW_FIELDS):
         scale = max(np.max(np.abs(b[k])), 1e-12)
         err = np.max(np.abs(a[k] - b[k])) / scale
-        assert err < FLOW_RTOL, f"{what}: {name}: {err:.3e} of the largest sum {scale:.3e}"
+        assert err < FLOW_RTOL[name], f"{what}: {name}: {err:.3e} of the largest sum {scale:.3e}"
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])

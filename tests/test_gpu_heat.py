@@ -61,6 +61,29 @@ def test_heat_ravone_window(product, oracle):
     run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), [2.0], max_steps=2)
 
 
+def test_statically_linked_caller_gives_the_same_numbers():
+    """shim/v2_static_demo = the same caller linked against shim/libsoilFluxes3D.a (shim built against
+    the reference's own headers, LinealiaLib stub, the .pro link line) - it answers main.cpp:81's LinealiaLib::instance().load()
+    with "not loaded" and prints the numbers of the dynamically linked demo."""
+    import os
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    demo, dyn = root / "shim" / "v2_static_demo", root / "shim" / "v2_caller_demo"
+    qt = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))
+    if not demo.exists() or not qt.exists():
+        pytest.skip("static demo not built (needs the reference headers + Qt at build time)")
+    # the image's Qt lives next to an older libstdc++: the system one first (criteria3d_amd/build.py)
+    env = dict(os.environ, LD_PRELOAD=f"/usr/lib/x86_64-linux-gnu/libstdc++.so.6 {qt}")
+    a = subprocess.run([str(demo)], capture_output=True, text=True, timeout=300, env=env)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run([str(dyn)], capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stdout + b.stderr
+    la = a.stdout.splitlines()
+    assert la[0] == "linealia loaded: 0"
+    assert [l for l in la if l.startswith("h")] == [l for l in b.stdout.splitlines() if l.startswith("h")]
+
+
 def test_cxx_caller_through_the_v2_symbols(oracle):
     """shim/v2_caller_demo: a C++ program written against the reference's public header (compiled against the reference's
     own soilFluxes3D.h where it is mounted) and linked to the drop-in library - water + heat on the C1-like column.

@@ -8,9 +8,15 @@
 #include "soilFluxes3D_api.h"
 #endif
 #include <cstdio>
+#ifdef SF3D_DEMO_LINEALIA
+#include "linealiaLib.h"      /* the application's main.cpp:81 asks the solver library for the optional linealia back end */
+#endif
 using namespace soilFluxes3D;
 int main()
 {
+#ifdef SF3D_DEMO_LINEALIA
+    printf("linealia loaded: %d\n", (int)LinealiaLib::instance().load());
+#endif
     const SF3Duint_t N = 22; const double dz = 0.05, area = 1.0, n = 1.56;
     if (initializeSF3D(N, 1, 8, true, true, false, heatFluxSaveMode_t::Total) != SF3Derror_t::SF3Dok) return 2;
     initializeHeatFlag(heatFluxSaveMode_t::Total, false, true);
