@@ -146,6 +146,7 @@ struct Ctrl {
 struct DistMail { unsigned long long seq; double v[3]; };
 struct DistWindow {                     /* head of each rank's window; payload doubles follow */
     DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
+    unsigned long long ping[SF3D_MAX_RANKS];   /* start-up self-check: peer p stores a token here through its mapping of this window */
 };
 struct DistView {
     int32_t world, rank;

@@ -88,6 +88,8 @@ struct DistBlob {
     uint32_t recvCount[SF3D_MAX_RANKS];
     uint32_t world, rank;
     uint64_t nodes;
+    uint32_t generation, pad;       /* export count of the rank; rank 0's value stamps the self-check token of a connect */
+    char pciBusId[32];             /* which physical GPU the rank runs on (start-up self-check: distinct, peer-reachable devices) */
 };
 
 /* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR

@@ -1784,6 +1784,8 @@ sf3d_error_t sf3d_compute_partition(const HostModel& m, int rank, int world, Par
     return SF3D_OK;
 }
 
+__global__ void k_dist_ping(DistView d, unsigned long long token, long long timeoutTicks, int* out);
+
 struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -1814,6 +1816,8 @@ struct DeviceSolver::Impl {
     DistView hostDist{};
     DistView* devDist = nullptr;
     uint32_t pushBlocks = 0;
+    uint32_t connectGen = 0;               /* token of the window self-check */
+    bool warnedShared = false;
     /* timing */
     int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
@@ -2568,6 +2572,8 @@ sf3d_error_t DeviceSolver::dist_export(HostModel& m, const ParamsHost& p, DistBl
     static_assert(sizeof(h) <= sizeof(out->ipcHandle), "ipc handle size");
     std::memcpy(out->ipcHandle, &h, sizeof(h));
     for (int r = 0; r < world_; ++r) { out->recvOff[r] = I.hostDist.recvOff[r]; out->recvCount[r] = I.hostDist.recvCount[r]; }
+    if (hipDeviceGetPCIBusId(out->pciBusId, (int)sizeof(out->pciBusId), I.device) != hipSuccess) out->pciBusId[0] = 0;
+    out->generation = ++I.connectGen;
     return SF3D_OK;
 }
 
@@ -2595,6 +2601,43 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
     }
     HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
     I.v.dist = I.devDist;
+    {   /* start-up self-check: distinct, peer-reachable devices, and one value through every window both ways */
+        static_assert(SF3D_MAX_RANKS >= 8, "a node has eight MI355X");
+        const bool shareOk = getenv("SF3D_BENCH_SHARE_GPU") && getenv("SF3D_BENCH_SHARE_GPU")[0] == '1';
+        const char* mine = all[rank_].pciBusId;
+        for (int r = 0; r < world_; ++r) {
+            if (r == rank_ || !mine[0] || !all[r].pciBusId[0]) continue;
+            if (std::strncmp(mine, all[r].pciBusId, sizeof(all[r].pciBusId)) == 0) {
+                if (!shareOk && !I.warnedShared) { fprintf(stderr, "sf3d: warning: ranks %d and %d run on the same GPU (%s): one process per GPU is the intended layout (set LOCAL_RANK / sf3d_set_device)\n", rank_, r, mine); I.warnedShared = true; }
+                continue;
+            }
+            int peerDev = -1, can = 1;
+            if (hipDeviceGetByPCIBusId(&peerDev, all[r].pciBusId) == hipSuccess && peerDev >= 0 && peerDev != I.device
+                && hipDeviceCanAccessPeer(&can, I.device, peerDev) == hipSuccess && !can) {
+                snprintf(err_, sizeof(err_), "dist_connect: GPU %s (rank %d) cannot access GPU %s (rank %d) peer-to-peer: the halo exchange needs P2P over xGMI/PCIe", mine, rank_, all[r].pciBusId, r);
+                return SF3D_SOLVER_ERROR;
+            }
+            (void)hipGetLastError();     /* a peer that is not visible to this process (one device per process) is checked by the ping alone */
+        }
+        double timeoutS = 5.0;
+        if (const char* te = getenv("SF3D_DIST_PING_TIMEOUT_S")) { const double t = atof(te); if (t > 0) timeoutS = t; }
+        int* dres = nullptr;
+        HIP_TRY(hipMalloc(&dres, sizeof(int) * SF3D_MAX_RANKS));
+        HIP_TRY(hipMemset(dres, 0, sizeof(int) * SF3D_MAX_RANKS));
+        const unsigned long long token = 0x5F3D000000000000ull + (unsigned long long)all[0].generation;    /* the same on every rank */
+        hipLaunchKernelGGL(k_dist_ping, dim3(1), dim3(64), 0, I.stream, d, token, (long long)(timeoutS * 1e8), dres);
+        int res[SF3D_MAX_RANKS] = {0};
+        hipError_t pe = hipMemcpyAsync(res, dres, sizeof(res), hipMemcpyDeviceToHost, I.stream);
+        if (pe == hipSuccess) pe = hipStreamSynchronize(I.stream);
+        (void)hipFree(dres);
+        if (pe != hipSuccess) { snprintf(err_, sizeof(err_), "dist_connect: window self-check failed: %s (cross-device IPC mapping unusable?)", hipGetErrorString(pe)); fatal_ = true; return SF3D_SOLVER_ERROR; }
+        int pos = 0; char who[128] = {0};
+        for (int r = 0; r < world_; ++r) if (!res[r]) pos += snprintf(who + pos, sizeof(who) - pos, " %d", r);
+        if (pos) {
+            snprintf(err_, sizeof(err_), "dist_connect: rank %d got no answer through the window of rank(s)%s within %.0f s (peer not connected, or device-initiated stores do not cross GPUs here)", rank_, who, timeoutS);
+            return SF3D_SOLVER_ERROR;
+        }
+    }
     connected_ = true;
     return SF3D_OK;
 }
@@ -2613,6 +2656,23 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
     mirror_ = *I.hostCtrl;
     *out = mirror_.query[0];
     return SF3D_OK;
+}
+
+/* start-up self-check of the sharded path (dist_connect): thread p stores a token into rank p's window through the IPC mapping
+ * (system-scope store over xGMI) and waits until rank p's token shows up in the own window; out[p] = 1 answered, 0 timed out */
+__global__ void k_dist_ping(DistView d, unsigned long long token, long long timeoutTicks, int* out)
+{
+    const int p = threadIdx.x;
+    if (p >= d.world) return;
+    if (p == d.rank) { out[p] = 1; return; }
+    __hip_atomic_store(&d.win[p]->ping[d.rank], token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();        /* 100 MHz */
+    int ok = 1;
+    while (__hip_atomic_load(&d.win[d.rank]->ping[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeoutTicks) { ok = 0; break; }
+    }
+    out[p] = ok;
 }
 
 __global__ void k_device_log(const double* x, double* y, uint32_t n)
