@@ -58,7 +58,7 @@ struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double clay, organicMatter;   /* heat only */
 };
 
-/* per-chunk link descriptor (144 bytes, fetched through the scalar path once per chunk) */
+/* per-chunk link descriptor (224 bytes, fetched through the scalar path once per chunk) */
 struct ChunkDesc {
     int32_t delta[SF3D_SLOTS];          /* j - i when kind[s] is a uniform link kind, else 0 */
     uint8_t kind[SF3D_SLOTS];           /* CK_NONE | LK_* (uniform) | CK_MIXED */
@@ -67,8 +67,12 @@ struct ChunkDesc {
     uint16_t areaUniform;               /* bit s: every link of slot s in the chunk has interface area area[s] */
     uint16_t sweepUniform;              /* bit s: kind[s] is CK_MIXED only because some nodes lack the link - every existing one has
                                          * j = i + delta[s] (row ends of a regular grid): the sweep needs no lto there */
-    uint8_t pad1[8];
+    uint16_t distUniform;               /* bit s: every link of slot s in the chunk has the link distance dist[s] */
+    uint8_t soilUniform;                /* 1: a soil-only chunk whose slots are all either empty or one uniform soil-soil link kind with uniform offset,
+                                         * area and distance (interior of a regular grid below layer 1): k_assemble's scalar-geometry path */
+    uint8_t pad1[5];
     double area[SF3D_SLOTS];            /* (cell size and layer thickness make it constant over regular grids) */
+    double dist[SF3D_SLOTS];
 };
 
 struct BalanceDev { double storage, sinkSource, MBE, MBR; };
@@ -110,6 +114,7 @@ struct Ctrl {
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
     uint32_t kfEpoch, haloEpoch, haloPar; int32_t haloBuf;   /* multi GPU: which exchange the many-block halo copies (k_halo_copy) belong to */
     int32_t acceptBuf;      /* pool index of the accepted H: the link flow sums of the step are added from it ... */
+    uint32_t aBuf, acceptABuf;   /* which A2x the step in progress uses / the accepted step used */
     double acceptDt;        /* ... with this dt, possibly while the next step's first kernels already run */
     /* ---- balances (balanceData_t x4, soilFluxes3D.cpp:37) ---- */
     BalanceDev curStep, prevStep, curPeriod, wholePeriod;
@@ -224,6 +229,9 @@ struct DevView {
     /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
+    /* the same chunks in the order the assembly walks them: [0, nListSurf) surface (k_assemble), [nListSurf, nAsmGen) soil chunks
+     * that need the general row code (k_assemble), [nAsmGen, nList) soil chunks with ChunkDesc::soilUniform (k_assemble_uniform) */
+    const uint32_t* asmList; uint32_t nAsmGen, nbAsmU;
     uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once
                                            per approximation (k_post) instead of once per sweep, off the critical path (SF3D_HALO_DIRECT=0: old way) */
     uint32_t ntStream;                  /* 1: streamed-once arrays (coefficients, link geometry, flow sums) bypass the caches
@@ -244,7 +252,10 @@ struct DevView {
     const uint8_t* lkind;               /* [10][N] */
     const double *larea, *ldist;        /* [10][N] interface area (read only where a chunk's areas differ) and link distance */
     double* lflowSum;                   /* [10][N] */
-    sf3d_d2* A2;                        /* [5][N] row-normalised off-diagonals, slots paired (2p, 2p+1): 16-byte accesses */
+    sf3d_d2* A2x[2];                    /* two copies of [5][N] row-normalised off-diagonals, slots paired (2p, 2p+1): 16-byte accesses.  The
+                                         * computeStep in progress assembles and sweeps A2x[Ctrl::aBuf]; k_step_begin flips aBuf, so the matrix of
+                                         * the step accepted before stays intact while its link flow sums are still being added (k_accept_links on the
+                                         * second stream, next to the whole next step instead of next to its k_props only) */
     double *b, *C;
     double* X[SF3D_POOL];
     double *Se, *SeHold, *K, *flow, *bflowRate, *bflowSum;   /* SeHold = Se(Hold), written at approximation 0 */

@@ -130,6 +130,9 @@ __device__ __forceinline__ double ppow(double x, double y)
 #endif
 }
 
+/* the coefficient matrix of the computeStep in progress */
+__device__ __forceinline__ sf3d_d2* cur_A2(const DevView& v) { return v.A2x[v.ctrl->aBuf & 1u]; }
+
 __device__ __forceinline__ int free_buffer(const Ctrl* c)
 {
     for (int b = 0; b < SF3D_POOL; ++b)
@@ -445,6 +448,7 @@ __device__ __forceinline__ void begin_attempt(Ctrl* c)
 __global__ void k_step_begin(Ctrl* c, double maxTimeStep)
 {
     c->maxTimeStep = maxTimeStep;
+    c->aBuf ^= 1u;              /* the matrix of the step accepted before stays intact for its link flow sums (k_accept_links) */
     begin_attempt(c);
 }
 
@@ -548,7 +552,7 @@ __device__ __forceinline__ void accept_bookkeeping(Ctrl* c)
     c->prevStep.sinkSource = c->curStep.sinkSource;
     c->curPeriod.sinkSource += c->curStep.sinkSource;
     c->counters[1]++;
-    c->acceptDt = c->dt; c->acceptBuf = c->cur;
+    c->acceptDt = c->dt; c->acceptBuf = c->cur; c->acceptABuf = c->aBuf;
     c->seSource = 1;                   /* Se = Se(H accepted): k_post, or k_restore for a restored best step */
     c->stage = ST_ACCEPT;              /* k_accept (flow sums) is the last kernel of the step */
 }
@@ -964,7 +968,7 @@ __device__ __forceinline__ void add_thermal_fluxes(const HeatDev& hv, uint32_t i
 /* scales the row (preconditioningMatrix, cpusolver.cpp:284-305), stores it, and leaves the scaled coefficients in k
  * and the right-hand side in the return value for the fused first sweep */
 template <bool NT>
-__device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& cd, uint32_t i, double (&k)[SF3D_SLOTS],
+__device__ __forceinline__ double store_row(const DevView& v, sf3d_d2* __restrict__ A2w, const ChunkDesc& cd, uint32_t i, double (&k)[SF3D_SLOTS],
                                             double sum, double Hoi, double dt, double invariantFlux, double Ci, double flowi)
 {
     const double cdt = Ci / dt;
@@ -974,7 +978,7 @@ __device__ __forceinline__ double store_row(const DevView& v, const ChunkDesc& c
     #pragma unroll
     for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
         k[2 * p] = (k[2 * p] * -1.) * inv; k[2 * p + 1] = (k[2 * p + 1] * -1.) * inv;
-        if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) store_coeff<NT>(&v.A2[(size_t)p * v.N + i], k[2 * p], k[2 * p + 1]);
+        if (cd.kind[2 * p] != CK_NONE || cd.kind[2 * p + 1] != CK_NONE) store_coeff<NT>(&A2w[(size_t)p * v.N + i], k[2 * p], k[2 * p + 1]);
     }
     const double bi = ((cdt * Hoi) + flowi + invariantFlux) * inv;   /* invariantFluxes: 0 without heat (cpusolver.cpp:148,387) */
     v.b[i] = bi;
@@ -1022,13 +1026,14 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
     const Ctrl* c = v.ctrl;
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
+    sf3d_d2* __restrict__ A2w = cur_A2(v);
     const double dt = c->dt;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     double courant = 0.;
     const uint32_t lane_ = threadIdx.x & 63u;
     for (uint32_t li_ = __builtin_amdgcn_readfirstlane(blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nListSurf;
          li_ += nblk * (SF3D_BLOCK / 64)) {
-        const uint32_t q = __builtin_amdgcn_readfirstlane(v.chunkList[li_]);
+        const uint32_t q = __builtin_amdgcn_readfirstlane(v.asmList[li_]);
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];
@@ -1051,7 +1056,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
             k[s] = ks;
             sum += ks;
         }
-        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
+        const double bi = store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
         if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
     }
     return block_max(courant);
@@ -1069,6 +1074,9 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
+#ifndef SF3D_ASM_UNIFORM_PATH
+#define SF3D_ASM_UNIFORM_PATH 1   /* scalar-geometry path for chunks whose ChunkDesc::soilUniform is set */
+#endif
 #ifndef SF3D_ASM_GROUPS
 #define SF3D_ASM_GROUPS 2      /* 2 groups of 5 slots (5 groups of 2, 1 of 10: tuning experiments) */
 #endif
@@ -1079,12 +1087,13 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
     const double dt = c->dt, lvRatio = c->lvRatio;
+    sf3d_d2* __restrict__ A2w = cur_A2(v);
     const uint32_t meanType = c->meanType;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     const uint32_t lane_ = threadIdx.x & 63u;
-    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nListSurf + blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nList;
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nListSurf + blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nAsmGen;
          li_ += nblk * (SF3D_BLOCK / 64)) {
-        const uint32_t q = __builtin_amdgcn_readfirstlane(v.chunkList[li_]);
+        const uint32_t q = __builtin_amdgcn_readfirstlane(v.asmList[li_]);
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
@@ -1135,8 +1144,57 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
 #endif
             }
         }
-        const double bi = store_row<NT>(v, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
+        const double bi = store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
         if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
+    }
+}
+
+/* Soil rows of the chunks whose link geometry is the chunk's (ChunkDesc::soilUniform: interior of a regular grid below layer 1,
+ * 75 % of the chunks of a 512-wide grid): link kind, neighbour offset, interface area and link distance of every slot sit in
+ * scalar registers, the only per-lane loads are Hold, K, C, waterFlow and the ten neighbour conductivities - all in flight before
+ * the first logarithm - and the row needs so few vector registers that more waves per SIMD hide the divide -> log -> divide
+ * chains of each other.  Same statements in the same order as assemble_soil_rows, hence the same bits.  Launched BEFORE
+ * k_assemble (whose last block takes the Courant decision and moves the stage on). */
+#ifndef SF3D_ASMU_WAVES
+#define SF3D_ASMU_WAVES 5
+#endif
+template <bool NT>
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASMU_WAVES) k_assemble_uniform(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_APPROX) return;
+    fm_init();
+    const double* __restrict__ Xh = v.X[c->hold];
+    const double dt = c->dt, lvRatio = c->lvRatio;
+    sf3d_d2* __restrict__ A2w = cur_A2(v);
+    const uint32_t meanType = c->meanType;
+    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
+    const uint32_t lane_ = threadIdx.x & 63u;
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nAsmGen + blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nList;
+         li_ += gridDim.x * (SF3D_BLOCK / 64)) {
+        const uint32_t q = __builtin_amdgcn_readfirstlane(v.asmList[li_]);
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (NOT_MINE(v, i)) continue;
+        const ChunkDesc& cd = v.cdesc[q];                               /* wave-uniform address: scalar loads, field by field */
+        const double Hoi = Xh[i], Ki = v.K[i], Ci = v.C[i], flowi = v.flow[i];
+        double kj[SF3D_SLOTS], k[SF3D_SLOTS];
+        #pragma unroll
+        for (int s = 0; s < SF3D_SLOTS; ++s) kj[s] = (cd.kind[s] != CK_NONE) ? v.K[i + cd.delta[s]] : 0.;
+        double sum = 0.;
+        #pragma unroll
+        for (int o = 0; o < SF3D_SLOTS; ++o) {
+            const uint32_t s = order[o];
+            double ks = 0.;
+            if (cd.kind[s] == LK_SOIL_LAT) {                             /* redistribution, water.cpp:542-562 */
+                const double ki = Ki * lvRatio, kn = kj[s] * lvRatio;
+                ks = (mean_of(ki, kn, meanType) * cd.area[s]) / cd.dist[s];
+            } else if (cd.kind[s] == LK_SOIL_VERT)
+                ks = (mean_of(Ki, kj[s], meanType) * cd.area[s]) / cd.dist[s];
+            k[s] = ks;
+            sum += ks;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, 0., Ci, flowi);
     }
 }
 
@@ -1189,13 +1247,14 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_compat_rows(DevView v)
     const bool surfOnly = c->asmSurfOnly != 0;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     const size_t N = v.N;
+    sf3d_d2* __restrict__ A2c = cur_A2(v);
     FOR_EACH_CHUNK_IN(v, 0u, surfOnly ? v.nListSurf : v.nList) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i) || (surfOnly && i >= v.ns)) continue;
         const ChunkDesc cd = v.cdesc[q];
         double a[SF3D_SLOTS];
         #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = v.A2[(size_t)p * N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2c[(size_t)p * N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
         const double diag = v.compatDiag[i];
         const double inv = surfOnly ? 1.0 : 1.0 / diag;
         uint32_t col = 1; bool lastDropped = false;
@@ -1212,7 +1271,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_compat_rows(DevView v)
         v.compatCv[i] = surfOnly ? diag : 1.0;
         if (!surfOnly) {
             #pragma unroll
-            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { sf3d_d2 t; t.x = a[2 * p] * inv; t.y = a[2 * p + 1] * inv; v.A2[(size_t)p * N + i] = t; }
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) { sf3d_d2 t; t.x = a[2 * p] * inv; t.y = a[2 * p + 1] * inv; A2c[(size_t)p * N + i] = t; }
             v.b[i] *= inv;
         }
     }
@@ -1225,9 +1284,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_compat_rows(DevView v)
  * the reference.  A zero coefficient adds exactly 0 - unless the compat storage exists: then a dropped
  * link reads the slot after the row's last column, like getMatrixElementValue (cpusolver.h:42-52). */
 template <bool NT>
-__device__ __forceinline__ void accept_links_row(const DevView& v, uint32_t q, uint32_t i, const double* __restrict__ X, double dt)
+__device__ __forceinline__ void accept_links_row(const DevView& v, const sf3d_d2* __restrict__ A2, uint32_t q, uint32_t i, const double* __restrict__ X, double dt)
 {
-    const sf3d_d2* __restrict__ A2 = v.A2;
     double a[SF3D_SLOTS], xj[SF3D_SLOTS], f[SF3D_SLOTS];
     uint32_t j[SF3D_SLOTS];
     #pragma unroll
@@ -1270,7 +1328,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     const uint32_t par = c->epoch & 1u;
     const double* __restrict__ xin = v.X[c->cur];
     double* __restrict__ xout = v.X[nxt];
-    const sf3d_d2* __restrict__ A2 = v.A2;
+    const sf3d_d2* __restrict__ A2 = cur_A2(v);
     double nrm = 0.;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
@@ -1401,6 +1459,7 @@ __global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(De
     int nxt1, nxt2;
     free_buffers2(c, nxt1, nxt2);
     const double* __restrict__ xin = v.X[c->cur];
+    const sf3d_d2* __restrict__ A2 = cur_A2(v);
     double* __restrict__ xo1 = v.X[nxt1];
     double* __restrict__ xo2 = v.X[nxt2];
     const int32_t NX = (int32_t)v.pair.NX, NY = (int32_t)v.pair.NY, NZ = (int32_t)v.pair.NZ;
@@ -1441,7 +1500,7 @@ __global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(De
                 if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
                 double xj[SF3D_SLOTS];
                 #pragma unroll
-                for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(v.A2 + (size_t)p * v.N, i)); ac[2 * p] = w.x; ac[2 * p + 1] = w.y; }
+                for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(A2 + (size_t)p * v.N, i)); ac[2 * p] = w.x; ac[2 * p + 1] = w.y; }
                 bc = *at32(v.b, i); zc = *at32(v.z, i);
                 const double xi = *at32(xin, i);
                 #pragma unroll
@@ -1648,11 +1707,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     const Ctrl* c = v.ctrl;
     if (c->stage != ST_ACCEPT) return;
     const double* __restrict__ X = v.X[c->cur];
+    const sf3d_d2* __restrict__ A2 = cur_A2(v);
     const double dt = c->dt;
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
-        accept_links_row<NT>(v, q, i, X, dt);
+        accept_links_row<NT>(v, A2, q, i, X, dt);
         if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
     }
 }
@@ -1672,15 +1732,16 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept_boundary(DevView v)
     }
 }
 template <bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_accept_links(DevView v)
+__global__ void __launch_bounds__(SF3D_BLOCK) k_accept_links(DevView v, int xbuf, uint32_t abuf, double dt)
 {
-    const Ctrl* c = v.ctrl;
-    const double* __restrict__ X = v.X[c->acceptBuf];
-    const double dt = c->acceptDt;
+    /* which head buffer, which copy of the matrix and which dt the accepted step had come as ARGUMENTS (the host has just polled
+     * them): this kernel runs next to the whole following computeStep, which overwrites those fields of the control block */
+    const double* __restrict__ X = v.X[xbuf];
+    const sf3d_d2* __restrict__ A2 = v.A2x[abuf & 1u];      /* the accepted step's matrix: the step in progress writes the other copy */
     FOR_EACH_CHUNK(v) {
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
-        accept_links_row<NT>(v, q, i, X, dt);
+        accept_links_row<NT>(v, A2, q, i, X, dt);
     }
 }
 
@@ -1790,8 +1851,8 @@ struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;         /* link flow sums of the accepted step, next to the next step's k_props */
-    hipEvent_t evLinks = nullptr;
-    bool linksPending = false;
+    hipEvent_t evLinks[2] = {nullptr, nullptr};   /* one per copy of the matrix: recorded after the link sums that read it */
+    bool linksPending[2] = {false, false};
     int overlapAccept = -1;                /* SF3D_OVERLAP_ACCEPT=0 keeps k_accept inside the step */
     DevView v{};
     Ctrl* hostCtrl = nullptr;              /* pinned */
@@ -1862,7 +1923,7 @@ sf3d_error_t DeviceSolver::release()
     Impl& I = *impl_;
     if (I.stream) hipStreamSynchronize(I.stream);
     if (I.stream2) hipStreamSynchronize(I.stream2);
-    I.linksPending = false;
+    I.linksPending[0] = I.linksPending[1] = false;
     for (auto& p : I.pending) { I.freeEvents.push_back(p.a); I.freeEvents.push_back(p.b); }
     I.pending.clear();
     for (auto& g : I.graphs) hipGraphExecDestroy(g.second);
@@ -1885,7 +1946,7 @@ sf3d_error_t DeviceSolver::synchronize()
 {
     if (!impl_ || !impl_->stream) return SF3D_OK;
     HIP_TRY(hipStreamSynchronize(impl_->stream));
-    if (impl_->stream2) { HIP_TRY(hipStreamSynchronize(impl_->stream2)); impl_->linksPending = false; }
+    if (impl_->stream2) { HIP_TRY(hipStreamSynchronize(impl_->stream2)); impl_->linksPending[0] = impl_->linksPending[1] = false; }
     return SF3D_OK;
 }
 
@@ -1920,7 +1981,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
     }
     HIP_TRY(hipSetDevice(I.device));
     if (!I.stream) HIP_TRY(hipStreamCreateWithFlags(&I.stream, hipStreamNonBlocking));
-    if (I.linksPending && (m.graphDirty || m.stateDirty || m.flowSumsDirty || !built_)) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending = false; }
+    if ((I.linksPending[0] || I.linksPending[1]) && (m.graphDirty || m.stateDirty || m.flowSumsDirty || !built_)) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending[0] = I.linksPending[1] = false; }
     if (!I.hostCtrl) HIP_TRY(hipHostMalloc((void**)&I.hostCtrl, sizeof(Ctrl), hipHostMallocDefault));
 
     const uint32_t N = m.N, ns = m.ns;
@@ -2018,7 +2079,23 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                             else if (area[e] != a0) uni = false;
                         }
                         if (uni) { d.areaUniform |= (uint16_t)(1u << s); d.area[s] = a0; }
+                        first = true; uni = true; double d0v = 0.;
+                        for (uint32_t i = i0; i < i1 && uni; ++i) {
+                            const size_t e = (size_t)s * N + i;
+                            if (kind[e] == LK_NONE) continue;
+                            if (first) { d0v = dist[e]; first = false; }
+                            else if (dist[e] != d0v) uni = false;
+                        }
+                        if (uni) { d.distUniform |= (uint16_t)(1u << s); d.dist[s] = d0v; }
                     }
+                }
+                {   /* scalar-geometry path of k_assemble: full 64-node soil chunk, every slot empty or uniform soil-soil */
+                    bool su = d.rowType == 1 && i1 - i0 == SF3D_CHUNK;
+                    for (int s = 0; s < SF3D_SLOTS && su; ++s) {
+                        if (d.kind[s] == CK_NONE) continue;
+                        su = (d.kind[s] == LK_SOIL_VERT || d.kind[s] == LK_SOIL_LAT) && ((d.areaUniform >> s) & 1u) && ((d.distUniform >> s) & 1u);
+                    }
+                    d.soilUniform = su ? 1 : 0;
                 }
                 cdesc[q] = d;
             }
@@ -2149,6 +2226,24 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             }
         }
 
+        std::vector<uint32_t> asmOrder(listSurf);                   /* listSurf now holds the whole list */
+        {
+            const char* ue = getenv("SF3D_ASM_UNIFORM");
+            const char* fe = getenv("SF3D_FUSE_FIRST_SWEEP");
+            /* the heat variant of the rows (thermal fluxes) and the fused first sweep live in k_assemble only */
+            /* OFF by default (SF3D_ASM_UNIFORM=1 turns it on): measured at C4, 166 us for the 71 % uniform chunks + 233 us for the rest, one
+             * after the other, against 300 us for everything in one launch - alone, the general rows (row ends, layer 1, surface) are
+             * latency-bound at 4 waves/SIMD; inside the single kernel their waiting is hidden by the other rows' arithmetic */
+            const bool want = !m.heat && (ue && ue[0] == '1') && !(fe && fe[0] == '1');
+            auto soilBegin = asmOrder.begin() + v.nListSurf;
+            auto mid = asmOrder.end();
+            if (want) mid = std::stable_partition(soilBegin, asmOrder.end(), [&](uint32_t q) { return cdesc[q].soilUniform == 0; });
+            v.nAsmGen = (uint32_t)(mid - asmOrder.begin());
+            const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
+            auto blocks = [&](uint32_t chunks) { uint32_t b = (chunks + per - 1) / per; if (b > SF3D_MAX_BLOCKS) b = SF3D_MAX_BLOCKS; return b; };
+            v.nbSoil = blocks(v.nAsmGen - v.nListSurf);
+            v.nbAsmU = blocks(v.nList - v.nAsmGen);
+        }
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness, *larea, *ldist;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
         HIP_TRY(dev_alloc(I.allocs, z, N)); HIP_TRY(dev_alloc(I.allocs, size, N));
@@ -2158,7 +2253,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(dev_alloc(I.allocs, prescribed, N));
         HIP_TRY(dev_alloc(I.allocs, lto, NS)); HIP_TRY(dev_alloc(I.allocs, lkind, NS));
         HIP_TRY(dev_alloc(I.allocs, larea, NS)); HIP_TRY(dev_alloc(I.allocs, ldist, NS));
-        HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A2, NS / 2));
+        HIP_TRY(dev_alloc(I.allocs, v.lflowSum, NS)); HIP_TRY(dev_alloc(I.allocs, v.A2x[0], NS / 2)); HIP_TRY(dev_alloc(I.allocs, v.A2x[1], NS / 2));
         HIP_TRY(dev_alloc(I.allocs, v.b, N)); HIP_TRY(dev_alloc(I.allocs, v.C, N));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(dev_alloc(I.allocs, v.X[k], N));
         HIP_TRY(dev_alloc(I.allocs, v.Se, N)); HIP_TRY(dev_alloc(I.allocs, v.K, N)); HIP_TRY(dev_alloc(I.allocs, v.SeHold, N));
@@ -2166,6 +2261,9 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         uint32_t* dlist; HIP_TRY(dev_alloc(I.allocs, dlist, listSurf.size()));
         if (!listSurf.empty()) HIP_TRY(hipMemcpy(dlist, listSurf.data(), listSurf.size() * 4, hipMemcpyHostToDevice));
         v.chunkList = dlist;
+        {   uint32_t* dasm; HIP_TRY(dev_alloc(I.allocs, dasm, asmOrder.size()));
+            if (!asmOrder.empty()) HIP_TRY(hipMemcpy(dasm, asmOrder.data(), asmOrder.size() * 4, hipMemcpyHostToDevice));
+            v.asmList = dasm; }
         v.owner = nullptr; v.dist = nullptr;
         {   /* bytes one rank touches per sweep: 152 B per owned node.  Below the 256 MiB Infinity Cache the whole
              * sweep working set stays cached between sweeps and bypassing costs ~8 % (measured at 0.98 M nodes);
@@ -2399,7 +2497,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpy(dcdesc, cdesc.data(), cdesc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
         if (!sd.empty()) HIP_TRY(hipMemcpy(soils, sd.data(), sd.size() * sizeof(SoilDev), hipMemcpyHostToDevice));
         if (!m.roughness.empty()) HIP_TRY(hipMemcpy(roughness, m.roughness.data(), m.roughness.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset(v.A2, 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
+        HIP_TRY(hipMemset(v.A2x[0], 0, NS * 8)); HIP_TRY(hipMemset(v.A2x[1], 0, NS * 8)); HIP_TRY(hipMemset(v.b, 0, N * 8)); HIP_TRY(hipMemset(v.C, 0, N * 8));
         HIP_TRY(hipMemset(v.flow, 0, N * 8)); HIP_TRY(hipMemset(v.bflowRate, 0, N * 8)); HIP_TRY(hipMemset(v.SeHold, 0, N * 8));
         for (int k = 0; k < SF3D_POOL; ++k) HIP_TRY(hipMemset(v.X[k], 0, N * 8));
         if (m.heat && I.heatAirP) hipLaunchKernelGGL(k_heat_static, dim3(v.nb), dim3(SF3D_BLOCK), 0, 0, v, I.heatAirP);
@@ -2485,7 +2583,7 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
 {
     Impl& I = *impl_;
     const size_t N = m.N;
-    if (I.stream2) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending = false; }     /* link flow sums of the last step */
+    if (I.stream2) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending[0] = I.linksPending[1] = false; }     /* link flow sums of the last step */
     HIP_TRY(hipMemcpyAsync(m.bflowSum.data(), I.v.bflowSum, N * 8, hipMemcpyDeviceToHost, I.stream));
     HIP_TRY(hipMemcpyAsync(m.bflowRate.data(), I.v.bflowRate, N * 8, hipMemcpyDeviceToHost, I.stream));
     for (int s = 0; s < SF3D_SLOTS; ++s)
@@ -2762,7 +2860,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
     if (I.fuseFirstSweep < 0) { const char* e = getenv("SF3D_FUSE_FIRST_SWEEP"); I.fuseFirstSweep = (e && e[0] == '1') ? 1 : 0; }   /* measured slower: off */
     const bool compat = v.compatCv != nullptr;   /* quirk-1 emulation: rows are stored raw and normalised by k_compat_rows after the Courant decision */
-    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat;      /* k_assemble also does the first Jacobi iteration */
+    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat && v.nAsmGen == v.nList;      /* k_assemble also does the first Jacobi iteration */
     /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
      * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
      * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
@@ -2793,10 +2891,10 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (I.overlapAccept < 0) { const char* oe = getenv("SF3D_OVERLAP_ACCEPT"); I.overlapAccept = (oe && oe[0] == '0') ? 0 : 1; }
     /* single GPU only: a second stream per process is a second hardware queue, and ranks that share a GPU (functional
      * multi-rank tests) oversubscribe the queues - their spinning exchange kernels then wait for time slices (measured: 45x slower) */
-    if (I.overlapAccept && !multi && !I.stream2) { HIP_TRY(hipStreamCreateWithFlags(&I.stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks, hipEventDisableTiming)); }
+    if (I.overlapAccept && !multi && !I.stream2) { HIP_TRY(hipStreamCreateWithFlags(&I.stream2, hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks[0], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&I.evLinks[1], hipEventDisableTiming)); }
     /* accepted step: link flow sums on a second stream next to the next step's k_props (untimed steps only, so that the
      * per-kernel event timing of --time-all-kernels stays a sequence of exclusive launches) */
-    const bool overlap = I.overlapAccept && !multi && I.stream2 && !timedStep && I.timing != 1;
+    const bool overlap = I.overlapAccept && !multi && I.stream2 && !timedStep && I.timing != 1 && v.compatCv == nullptr;   /* (compat: k_compat_rows rewrites what the sums read) */
     auto timed = [&](int kid, auto launch) {
         if (!timedStep || (I.timing == 2 && kid != KID_SWEEP && kid != KID_SWEEP_PAIR)) { launch(); return; }
         hipEvent_t a, b;
@@ -2813,6 +2911,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     }
     uint32_t stage = ST_ACCEPT;
     if (m.water) {
+    {   /* this step assembles into the copy of the matrix that the step before the last one used (k_step_begin flips Ctrl::aBuf): the
+         * link flow sums that read it - queued two steps ago on the second stream - must be done; so must they before this step's
+         * sweeps reuse the head buffer they read.  The sums of the LAST step run next to this whole step. */
+        const uint32_t wb = (mirror_.aBuf ^ 1u) & 1u;
+        if (I.linksPending[wb]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb], 0)); I.linksPending[wb] = false; }
+    }
     hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
     stage = ST_APPROX;                      /* k_step_begin opens the first attempt */
     uint64_t before[8], atStart[8];
@@ -2838,15 +2942,23 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
     };
+    /* the soil rows with chunk-uniform link geometry: their own low-register kernel, queued before k_assemble (which decides) */
+    const dim3 asmUGrid = [&] { const dim3 r = v.ntStream ? resident((const void*)k_assemble_uniform<true>) : resident((const void*)k_assemble_uniform<false>);
+                                return dim3(v.nbAsmU < r.x ? (v.nbAsmU ? v.nbAsmU : 1u) : r.x); }();
+    auto launch_uniform_rows = [&] {
+        if (v.nAsmGen >= v.nList) return;
+        if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
+        else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, st, v);
+    };
     auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps) {
         if (withHead) {
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
             else if (fuse0) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
-            else if (I.useFused) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
-                timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
@@ -2922,16 +3034,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     while (true) {
         for (uint32_t bq = 0; bq < look; ++bq) {
             const bool head = bq > 0 || stage == ST_APPROX;
-            bool skipProps = false;
-            if (head && I.linksPending) {
-                /* the previous step's link flow sums may still be reading A2 on the second stream: this step's k_props
-                 * runs next to them, the first k_assemble (which rewrites A2) waits for them */
-                enqueue_props();
-                HIP_TRY(hipStreamWaitEvent(st, I.evLinks, 0));
-                I.linksPending = false;
-                skipProps = true;
-            }
-            HIP_TRY(launch_batch(head, bq + 1 == look, skipProps));
+            HIP_TRY(launch_batch(head, bq + 1 == look, false));
         }
         look = 1;
         HIP_TRY(hipGetLastError());
@@ -2978,10 +3081,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         /* the main stream is drained (the poll just read the control block): no dependency to express for the launch */
         uint32_t lcap = 384u; if (const char* le = getenv("SF3D_LINKS_BLOCKS")) lcap = (uint32_t)atoi(le);      /* measured at C4: 2048 -1 %, 512 / 256 +1 %, 128 -4 % */
         const dim3 lgrid(v.nb > lcap ? lcap : v.nb);        /* a streaming kernel: few enough waves that k_props fits next to it */
-        if (v.ntStream) hipLaunchKernelGGL(k_accept_links<true>, lgrid, block, 0, I.stream2, v);
-        else hipLaunchKernelGGL(k_accept_links<false>, lgrid, block, 0, I.stream2, v);
-        HIP_TRY(hipEventRecord(I.evLinks, I.stream2));
-        I.linksPending = true;
+        const Ctrl& hc = *I.hostCtrl;
+        const uint32_t rb = hc.acceptABuf & 1u;
+        if (v.ntStream) hipLaunchKernelGGL(k_accept_links<true>, lgrid, block, 0, I.stream2, v, hc.acceptBuf, rb, hc.acceptDt);
+        else hipLaunchKernelGGL(k_accept_links<false>, lgrid, block, 0, I.stream2, v, hc.acceptBuf, rb, hc.acceptDt);
+        HIP_TRY(hipEventRecord(I.evLinks[rb], I.stream2));
+        I.linksPending[rb] = true;
     }
     }   /* if (m.water) */
 
