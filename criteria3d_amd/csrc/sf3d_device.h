@@ -132,6 +132,8 @@ struct Ctrl {
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
     /* ---- quirk-1 compat (SF3D_COMPAT_STALE_LINK_FLOW=1): which assembly k_compat_rows has to mirror into the emulated row storage ---- */
+    uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
+    uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
     uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */
     uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
     uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */
@@ -267,6 +269,7 @@ struct DevView {
     double* compatCv; uint8_t* compatCn; double* compatDiag;
     double *part0, *part1;              /* per-block partials [nb] */
     unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
+    unsigned int* gridBar;              /* arrival counter of the persistent step kernel's grid barrier (monotonic) */
     const SoilDev* soils;
     const double* roughness;
     PairGrid pair;

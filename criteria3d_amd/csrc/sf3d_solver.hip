@@ -775,10 +775,9 @@ __device__ __forceinline__ double dtheta_dh_cached(const SoilDev& s, double H, d
                                 * 150 -> 135 us at C4 against 4 waves, launched with exactly the 1 280 resident blocks */
 #endif
 template <int MODE, bool HEAT>
-__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_PROPS_HEAT_WAVES : SF3D_PROPS_WAVES) k_props(DevView v)
+__device__ __forceinline__ void body_props(const DevView& v)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_APPROX) return;
     fm_init();
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
@@ -836,6 +835,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_PROPS_HEAT_WAVES : SF3
     double vals[3] = {0., 0., 0.};
     if (!dist_allgather(v, v.ctrl, vals, 0)) return;          /* the barrier: every neighbour's K and waterFlow have landed */
     if (threadIdx.x == 0) v.ctrl->kfEpoch = v.ctrl->epoch;     /* k_halo_copy<0> (next launch, many blocks) copies them in */
+}
+template <int MODE, bool HEAT>
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_PROPS_HEAT_WAVES : SF3D_PROPS_WAVES) k_props(DevView v)
+{
+    if (v.ctrl->stage != ST_APPROX) return;
+    body_props<MODE, HEAT>(v);
 }
 
 /* The halo copies that used to run in the ONE block that closes an exchange (20 000 system-scope loads at 8-way C4,
@@ -1206,18 +1211,21 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASMU_WAVES) k_assemble_unifor
  * one k_sweep launch less per approximation.  After a failed Courant check the swept values sit in a free buffer and are
  * never looked at.  Same results, but off by default: at 4 waves/SIMD the eleven extra gathers cost k_assemble 186 us, more
  * than the 126 us sweep they replace. */
-template <bool FUSED, bool NT, bool HEAT, bool SWEEP0 = false>
-__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
+template <bool FUSED, bool NT, bool HEAT, bool SWEEP0, bool ALLROWS>
+__device__ __forceinline__ void body_assemble(const DevView& v)
 {
-    if (v.ctrl->stage != ST_APPROX) return;
     fm_init();
     const int nxt = free_buffer(v.ctrl);                  /* where k_sweep would write its first iterate */
     double* __restrict__ xout = v.X[nxt];
     double bm = 0., nrm = 0.;
-    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, v.nbSurf, xout, nrm);
+    if (ALLROWS) {          /* persistent step kernel: every block takes its share of the surface rows, then of the soil rows */
+        bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, gridDim.x, xout, nrm);
+        assemble_soil_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, gridDim.x, xout, nrm);
+    }
+    else if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, v.nbSurf, xout, nrm);
     else assemble_soil_rows<NT, HEAT, SWEEP0>(v, blockIdx.x - v.nbSurf, v.nbSoil, xout, nrm);
     if (!FUSED) {
-        if (threadIdx.x == 0 && blockIdx.x < v.nbSurf) v.part0[blockIdx.x] = bm;
+        if (threadIdx.x == 0 && (ALLROWS || blockIdx.x < v.nbSurf)) v.part0[blockIdx.x] = bm;
         return;
     }
     const double bs = SWEEP0 ? block_sum(nrm) : 0.;
@@ -1233,6 +1241,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_
         courant_decision(v.ctrl, vals[0]);
         if (SWEEP0 && v.ctrl->stage == ST_SWEEP) sweep_decision(v.ctrl, nxt, norm / v.N);
     }
+}
+template <bool FUSED, bool NT, bool HEAT, bool SWEEP0 = false>
+__global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
+{
+    if (v.ctrl->stage != ST_APPROX) return;
+    body_assemble<FUSED, NT, HEAT, SWEEP0, false>(v);
 }
 
 /* quirk-1 compat only.  Mirrors the assembly that has just been decided into the emulated row storage of the reference
@@ -1320,10 +1334,9 @@ __device__ __forceinline__ void accept_links_row(const DevView& v, const sf3d_d2
  * the new iterate of its boundary nodes into the neighbours' windows, and the last block all-gathers
  * the norm, copies the received halo and decides - one launch per sweep in every configuration. */
 template <int MODE, bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
+__device__ __forceinline__ void body_sweep(const DevView& v)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP) return;
     const int nxt = free_buffer(c);
     const uint32_t par = c->epoch & 1u;
     const double* __restrict__ xin = v.X[c->cur];
@@ -1395,6 +1408,12 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
         if (!v.haloDirect) dist_unpack(v, par, DF_X, v.X[nxt]);           /* neighbours' new iterate on my halo */
     }
     if (threadIdx.x == 0) sweep_decision(v.ctrl, nxt, vals[0] / v.N);
+}
+template <int MODE, bool NT>
+__global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
+{
+    if (v.ctrl->stage != ST_SWEEP) return;
+    body_sweep<MODE, NT>(v);
 }
 
 /* ---- two Jacobi iterations per pass over the coefficient stream (regular grids, one GPU) -------------------------------------
@@ -1600,10 +1619,9 @@ __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, u
 #define SF3D_POST_WAVES 8      /* 64 VGPRs: all 2 048 blocks of the grid resident at once (at 70 VGPRs 1 792 are, and the rest form a tail) */
 #endif
 template <bool FUSED>
-__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_POST_WAVES) k_post(DevView v)
+__device__ __forceinline__ void body_post(const DevView& v)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_POST) return;
     fm_init();
     const int cur = c->cur;
     const uint32_t parLastSweep = (c->epoch - 1u) & 1u;       /* the last sweep put its iterate one epoch ago */
@@ -1652,13 +1670,18 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_POST_WAVES) k_post(DevView v)
         balance_decision(v.ctrl, vals[0], vals[1]);
     }
 }
+template <bool FUSED>
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_POST_WAVES) k_post(DevView v)
+{
+    if (v.ctrl->stage != ST_POST) return;
+    body_post<FUSED>(v);
+}
 
 /* restoreBestStep, water.cpp:253-267 */
 template <bool FUSED, bool HEAT>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
+__device__ __forceinline__ void body_restore(const DevView& v)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_RESTORE) return;
     fm_init();
     const double* __restrict__ Xc = v.X[c->cur];
     const double* __restrict__ Xh = v.X[c->hold];
@@ -1699,13 +1722,18 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
     if (haloK) dist_unpack(v, par, DF_K, v.K);
     if (threadIdx.x == 0) restore_decision(v.ctrl, vals[0], vals[1]);
 }
+template <bool FUSED, bool HEAT>
+__global__ void __launch_bounds__(SF3D_BLOCK) k_restore(DevView v)
+{
+    if (v.ctrl->stage != ST_RESTORE) return;
+    body_restore<FUSED, HEAT>(v);
+}
 
 /* acceptStep flow sums, water.cpp:240-250 + updateLinkFlux :269-277 */
 template <bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
+__device__ __forceinline__ void body_accept(const DevView& v)
 {
     const Ctrl* c = v.ctrl;
-    if (c->stage != ST_ACCEPT) return;
     const double* __restrict__ X = v.X[c->cur];
     const sf3d_d2* __restrict__ A2 = cur_A2(v);
     const double dt = c->dt;
@@ -1714,6 +1742,96 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
         if (NOT_MINE(v, i)) continue;
         accept_links_row<NT>(v, A2, q, i, X, dt);
         if (v.btype[i] != SF3D_BND_NONE) v.bflowSum[i] += v.bflowRate[i] * dt;
+    }
+}
+template <bool NT>
+__global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
+{
+    if (v.ctrl->stage != ST_ACCEPT) return;
+    body_accept<NT>(v);
+}
+
+/* ---- one computeStep in ONE launch: small grids in the runoff regime ------------------------------------------------------
+ * A step there is ~25 launches of a few microseconds of work each (C2 F60: 2.6 approximations and 12 sweeps per step, dt
+ * pinned at dtmin, 5 500 steps per simulated hour): kernel boundaries cost more than the kernels.  This kernel walks the same
+ * stage machine with the same phase bodies - body_props / body_assemble / body_sweep / body_post / body_restore / body_accept,
+ * decisions in the block that arrives last - and puts a grid barrier where the kernel boundaries were.  All blocks are resident
+ * at once (the host sizes the grid from the occupancy query), every block takes the same branch because the stage only changes
+ * inside a phase, before the barrier that ends it.  Between phases: agent-scope release before the arrival (this XCD's L2 is
+ * written back: the next phase reads across XCDs), acquire + scalar-cache invalidate after it (the control block is read
+ * through the scalar path and changes from phase to phase).  A bounded wait turns blocks that are not co-resident into a failed
+ * step instead of a hung GPU. */
+__device__ __forceinline__ bool grid_barrier(const DevView& v, unsigned int& gen)
+{
+    __shared__ int sOk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        gen += gridDim.x;
+        __hip_atomic_fetch_add(v.gridBar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(v.gridBar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 300000000LL) { ok = 0; break; }      /* 3 s at 100 MHz */
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        sOk = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();       /* (the vector L1 of this CU was invalidated by thread 0's acquire) */
+    return sOk != 0;
+}
+
+#ifndef SF3D_PERSIST_WAVES
+#define SF3D_PERSIST_WAVES 2      /* all six phases in one body need ~230 VGPRs; the grids this kernel serves fill the GPU with two waves per SIMD or fewer */
+#endif
+/* the phases, inlined: the view stays a kernel argument (scalar registers, global address space).  SF3D_PHASE_NOINLINE=1 compiles
+ * them as real functions instead (own register allocation each, but the view then travels through memory and its pointers
+ * become generic: measured slower) */
+#ifndef SF3D_PHASE_NOINLINE
+#define SF3D_PHASE_NOINLINE 0
+#endif
+#if SF3D_PHASE_NOINLINE
+#define SF3D_PHASE __device__ __attribute__((noinline)) void
+#define SF3D_PHASE_B __device__ __attribute__((noinline)) bool
+#else
+#define SF3D_PHASE __device__ __forceinline__ void
+#define SF3D_PHASE_B __device__ __forceinline__ bool
+#endif
+SF3D_PHASE phase_props(const DevView& v) { body_props<0, false>(v); }
+template <bool NT> SF3D_PHASE phase_assemble(const DevView& v) { body_assemble<true, NT, false, false, true>(v); }
+template <bool NT> SF3D_PHASE phase_sweep(const DevView& v) { body_sweep<1, NT>(v); }
+SF3D_PHASE phase_post(const DevView& v) { body_post<true>(v); }
+SF3D_PHASE phase_restore(const DevView& v) { body_restore<true, false>(v); }
+template <bool NT> SF3D_PHASE phase_accept(const DevView& v) { body_accept<NT>(v); }
+SF3D_PHASE_B phase_barrier(const DevView& v, unsigned int& gen) { return grid_barrier(v, gen); }
+
+template <bool NT>
+__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_PERSIST_WAVES) k_step_persistent(DevView v, double maxTimeStep)
+{
+    Ctrl* c = v.ctrl;
+    unsigned int gen = __hip_atomic_load(&c->barGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->maxTimeStep = maxTimeStep; c->aBuf ^= 1u; begin_attempt(c); }
+    bool ok = phase_barrier(v, gen);
+    for (uint32_t guard = 0; ok && guard < 100000u; ++guard) {
+        const uint32_t stage = __hip_atomic_load(&c->stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stage == ST_APPROX) {
+            phase_props(v);
+            ok = phase_barrier(v, gen);
+            if (!ok) break;
+            phase_assemble<NT>(v);
+        }
+        else if (stage == ST_SWEEP) phase_sweep<NT>(v);
+        else if (stage == ST_POST) phase_post(v);
+        else if (stage == ST_RESTORE) phase_restore(v);
+        else if (stage == ST_ACCEPT) { phase_accept<NT>(v); break; }
+        else break;                                            /* ST_FAIL */
+        ok = phase_barrier(v, gen);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!ok) { c->barTimeout = 1; c->stage = ST_FAIL; }
+        c->barGen = gen;          /* every block made the same number of barriers: the next launch starts from here */
     }
 }
 
@@ -1884,6 +2002,8 @@ struct DeviceSolver::Impl {
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
     int fuseFirstSweep = -1;              /* SF3D_FUSE_FIRST_SWEEP=1: k_assemble also does the first Jacobi iteration (measured slower) */
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
+    int persistent = -1;                   /* -1 not decided yet for this model, 0 off, 1: one launch per computeStep (k_step_persistent) */
+    uint32_t persistBlocks = 0;
     uint32_t pairBlocks = 0;              /* grid of k_sweep_pair (0: the graph is no regular grid, or the paired sweep is off) */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
@@ -1939,6 +2059,7 @@ sf3d_error_t DeviceSolver::release()
     fatal_ = false;
     /* the SF3D_* mode switches are read again when the next model is built (tests toggle them between models of one process) */
     I.overlapAccept = I.useFused = I.useGraphs = I.fuseFirstSweep = I.residentGrids = -1;
+    I.persistent = -1; I.persistBlocks = 0;
     return SF3D_OK;
 }
 
@@ -2394,6 +2515,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, I.pairBlocks) + 8;
             HIP_TRY(dev_alloc(I.allocs, v.part0, np)); HIP_TRY(dev_alloc(I.allocs, v.part1, np)); }
         HIP_TRY(dev_alloc(I.allocs, v.arrive, 16 * 17)); HIP_TRY(hipMemset(v.arrive, 0, 16 * 17 * sizeof(unsigned int)));
+        HIP_TRY(dev_alloc(I.allocs, v.gridBar, 16)); HIP_TRY(hipMemset(v.gridBar, 0, 16 * sizeof(unsigned int)));
         HIP_TRY(dev_alloc(I.allocs, soils, m.soils.size())); HIP_TRY(dev_alloc(I.allocs, roughness, m.roughness.size()));
         HIP_TRY(dev_alloc(I.allocs, v.ctrl, 1));
         v.z = z; v.size = size; v.pond = pond; v.sink = sink; v.cls = cls; v.btype = btype;
@@ -2911,12 +3033,46 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     }
     uint32_t stage = ST_ACCEPT;
     if (m.water) {
+    if (I.persistent < 0) {
+        /* one launch per computeStep for small grids (kernel boundaries cost more than the kernels there): one GPU, water only, plain
+         * sweeps; automatic below SF3D_PERSISTENT_MAX_NODES (default 1.5 M nodes), SF3D_PERSISTENT=0/1 forces */
+        const char* pe = getenv("SF3D_PERSISTENT");
+        double maxNodes = 1.5e6; if (const char* me = getenv("SF3D_PERSISTENT_MAX_NODES")) maxNodes = atof(me);
+        bool on = !multi && !heatOn && !compat && I.useFused && I.pairBlocks == 0 && v.nAsmGen == v.nList && !fuse0;
+        /* OFF unless SF3D_PERSISTENT=1: measured on MI355X the grid barrier (agent-scope release: L2 write-back, arrival, spin, acquire:
+         * invalidate - by every block) costs MORE than a kernel boundary of a graph replay: C2 F60 0.384 ms/step against 0.263,
+         * C3 F60 1.69 against 0.81 */
+        on = on && pe && pe[0] == '1' && (double)v.N <= maxNodes * 1e3;
+        I.persistent = 0;
+        if (on) {
+            int perCu = 0, dev = 0; hipDeviceProp_t prop;
+            const void* fn = v.ntStream ? (const void*)k_step_persistent<true> : (const void*)k_step_persistent<false>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, SF3D_BLOCK, 0) == hipSuccess && perCu > 0 && hipGetDevice(&dev) == hipSuccess
+                && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
+                const uint32_t res = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;      /* all blocks must be resident at once */
+                I.persistBlocks = v.nb < res ? v.nb : res;
+                I.persistent = 1;
+            }
+        }
+    }
+    const bool persistentStep = I.persistent == 1 && !timedStep && I.timing != 1;
     {   /* this step assembles into the copy of the matrix that the step before the last one used (k_step_begin flips Ctrl::aBuf): the
          * link flow sums that read it - queued two steps ago on the second stream - must be done; so must they before this step's
-         * sweeps reuse the head buffer they read.  The sums of the LAST step run next to this whole step. */
+         * sweeps reuse the head buffer they read.  The sums of the LAST step run next to this whole step - unless this step adds its
+         * own sums inside the step (event-timed steps, the persistent kernel): then both must be done first. */
         const uint32_t wb = (mirror_.aBuf ^ 1u) & 1u;
         if (I.linksPending[wb]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb], 0)); I.linksPending[wb] = false; }
+        if ((!overlap || persistentStep) && I.linksPending[wb ^ 1u]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb ^ 1u], 0)); I.linksPending[wb ^ 1u] = false; }
     }
+    if (persistentStep) {
+        if (v.ntStream) hipLaunchKernelGGL(k_step_persistent<true>, dim3(I.persistBlocks), block, 0, st, v, maxTimeStep);
+        else hipLaunchKernelGGL(k_step_persistent<false>, dim3(I.persistBlocks), block, 0, st, v, maxTimeStep);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        stage = I.hostCtrl->stage;
+        if (I.hostCtrl->barTimeout) { snprintf(err_, sizeof(err_), "persistent step kernel: a grid barrier timed out (blocks not resident together? another process on the GPU?): set SF3D_PERSISTENT=0"); fatal_ = true; }
+    } else {
     hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
     stage = ST_APPROX;                      /* k_step_begin opens the first attempt */
     uint64_t before[8], atStart[8];
@@ -3077,7 +3233,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         const uint64_t used = I.hostCtrl->counters[2] - atStart[2];
         I.lastBatches = used < 1 ? 1u : (uint32_t)used;
     }
-    if (overlap && stage == ST_ACCEPT) {
+    }   /* !persistentStep */
+    if (overlap && !persistentStep && stage == ST_ACCEPT) {
         /* the main stream is drained (the poll just read the control block): no dependency to express for the launch */
         uint32_t lcap = 384u; if (const char* le = getenv("SF3D_LINKS_BLOCKS")) lcap = (uint32_t)atoi(le);      /* measured at C4: 2048 -1 %, 512 / 256 +1 %, 128 -4 % */
         const dim3 lgrid(v.nb > lcap ? lcap : v.nb);        /* a streaming kernel: few enough waves that k_props fits next to it */
