@@ -132,6 +132,8 @@ struct Ctrl {
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
     /* ---- quirk-1 compat (SF3D_COMPAT_STALE_LINK_FLOW=1): which assembly k_compat_rows has to mirror into the emulated row storage ---- */
+    uint32_t seqCount, seqSweeps[16];   /* Jacobi iterations of the 1st, 2nd, ... approximation of the computeStep in progress (0 for one the Courant check
+                                          * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
     uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
     uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */

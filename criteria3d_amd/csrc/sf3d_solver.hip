@@ -448,6 +448,7 @@ __device__ __forceinline__ void begin_attempt(Ctrl* c)
 __global__ void k_step_begin(Ctrl* c, double maxTimeStep)
 {
     c->maxTimeStep = maxTimeStep;
+    c->seqCount = 0;
     c->aBuf ^= 1u;              /* the matrix of the step accepted before stays intact for its link flow sums (k_accept_links) */
     begin_attempt(c);
 }
@@ -482,6 +483,8 @@ __device__ __forceinline__ void courant_decision(Ctrl* c, double cmax)
     for (int k = 0; k < mult; ++k) d /= 10.;
     c->dtCurr = dmax(c->dtMin, d);
     c->counters[4]++;
+    if (c->seqCount < 16u) c->seqSweeps[c->seqCount] = 0;
+    c->seqCount++;
     reject_attempt(c);
 }
 __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_courant(DevView v)
@@ -508,6 +511,8 @@ __device__ __forceinline__ void sweep_decision(Ctrl* c, int nxt, double norm)
         if (c->iter >= c->iterBudget) done = true;
     }
     if (!done) return;
+    if (c->seqCount < 16u) c->seqSweeps[c->seqCount] = c->iter;
+    c->seqCount++;
     c->linearValid = valid ? 1 : 0;
     if (!valid) c->counters[5]++;
     if (!valid && c->dt > c->dtMin) {
@@ -1812,7 +1817,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_PERSIST_WAVES) k_step_persist
 {
     Ctrl* c = v.ctrl;
     unsigned int gen = __hip_atomic_load(&c->barGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c->maxTimeStep = maxTimeStep; c->aBuf ^= 1u; begin_attempt(c); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->maxTimeStep = maxTimeStep; c->seqCount = 0; c->aBuf ^= 1u; begin_attempt(c); }
     bool ok = phase_barrier(v, gen);
     for (uint32_t guard = 0; ok && guard < 100000u; ++guard) {
         const uint32_t stage = __hip_atomic_load(&c->stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1978,6 +1983,7 @@ struct DeviceSolver::Impl {
     uint32_t N = 0, ns = 0;
     uint32_t lastSweeps = 8;
     uint32_t lastBatches = 1;
+    uint32_t predCount = 0, pred[16] = {0};   /* sweeps each approximation of the previous computeStep took (Ctrl::seqSweeps) */
     uint32_t lastHeatSweeps = 8;
     std::vector<uint32_t> gsLevelStart;    /* SF3D_HEAT_GS=1: level l = gsOrder[gsLevelStart[l] .. gsLevelStart[l+1]) */
     uint32_t lastHeatSteps = 1;            /* heat steps (accepted + halved) of the previous computeStep: look-ahead depth */
@@ -3106,7 +3112,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
         else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, st, v);
     };
-    auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps) {
+    auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) {
         if (withHead) {
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
@@ -3119,9 +3125,6 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
         }
         if (withHead && compat) hipLaunchKernelGGL(k_compat_rows, grid, block, 0, st, v);
-        uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
-        if (chunk < 4) chunk = 4;
-        if (chunk > 40) chunk = 40;
         if (pairOn) {      /* two Jacobi iterations per launch (regular grid, one GPU): ceil(chunk / 2) launches */
             const dim3 pgr(I.pairBlocks), pbl((v.pair.W + 1) * 64);
             for (uint32_t k = 0; k < (chunk + 1) / 2; ++k)
@@ -3166,17 +3169,24 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* The ~25 launches of a batch are replayed from an instantiated hipGraph (one per shape): small
      * grids are bound by the host's launch rate otherwise.  Event timing needs eager launches. */
     if (I.useGraphs < 0) { const char* e = getenv("SF3D_GRAPHS"); I.useGraphs = (e && e[0] == '0') ? 0 : 1; }
-    auto launch_batch = [&](bool withHead, bool withTail, bool skipProps) -> hipError_t {
-        if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps); return hipSuccess; }
-        uint32_t chunk = I.lastSweeps + (fuse0 ? 1 : 2);      /* fuse0: the first iteration is done by k_assemble */
-        if (chunk < 4) chunk = 4;
+    /* how many sweeps to queue for the `index`-th approximation of this step: what the same approximation of the previous step took,
+     * plus one (Ctrl::seqSweeps; a sweep queued in vain is a guarded no-op of ~4 us, one too few costs a poll; sweeps that a later
+     * batch queued simply continue an unfinished approximation); without a record, the last count plus two */
+    auto predicted_sweeps = [&](uint32_t index, bool withHead) -> uint32_t {
+        uint32_t chunk;
+        if (withHead && index < I.predCount && index < 16u) { chunk = I.pred[index] + 1; if (fuse0 && chunk > 1) --chunk; if (chunk < 2) chunk = 2; }
+        else { chunk = I.lastSweeps + (fuse0 ? 1 : 2); if (chunk < 4) chunk = 4; }      /* fuse0: the first iteration is done by k_assemble */
         if (chunk > 40) chunk = 40;
+        return chunk;
+    };
+    auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
+        if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }
         const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) return e;
-        enqueue_batch(withHead, withTail, skipProps);
+        enqueue_batch(withHead, withTail, skipProps, chunk);
         e = hipStreamEndCapture(st, &graph);
         if (e != hipSuccess) return e;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -3187,10 +3197,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     };
 
     uint32_t look = I.lastBatches < 1 ? 1 : (I.lastBatches > 6 ? 6 : I.lastBatches);
+    uint32_t batchIndex = 0;
     while (true) {
         for (uint32_t bq = 0; bq < look; ++bq) {
             const bool head = bq > 0 || stage == ST_APPROX;
-            HIP_TRY(launch_batch(head, bq + 1 == look, false));
+            HIP_TRY(launch_batch(head, bq + 1 == look, false, predicted_sweeps(batchIndex, head)));
+            if (head) ++batchIndex;
         }
         look = 1;
         HIP_TRY(hipGetLastError());
@@ -3232,6 +3244,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     {   /* approximations this step took (rejected attempts included) = batches the next one will queue up front */
         const uint64_t used = I.hostCtrl->counters[2] - atStart[2];
         I.lastBatches = used < 1 ? 1u : (uint32_t)used;
+        I.predCount = I.hostCtrl->seqCount < 16u ? I.hostCtrl->seqCount : 16u;
+        for (uint32_t k = 0; k < I.predCount; ++k) I.pred[k] = I.hostCtrl->seqSweeps[k];
     }
     }   /* !persistentStep */
     if (overlap && !persistentStep && stage == ST_ACCEPT) {
