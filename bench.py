@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--heat", action="store_true", help="coupled heat transport (latent heat, atmosphere boundary on every top soil cell)")
     ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
+    ap.add_argument("--lineal", action="store_true", help="setUseLineal(true) with the device conjugate gradients (SF3D_LINEAL_DEVICE_CG=1) instead of Jacobi sweeps: not the headline path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
@@ -253,9 +254,14 @@ def main():
         heat = cm.Heat(water=True, latent=True, save_mode=0)
     log(f"[bench] rank {rank}: {args.workload} model arrays in {time.perf_counter() - t0:.1f}s ({model.n} nodes)")
 
+    if args.lineal:
+        os.environ["SF3D_LINEAL_DEVICE_CG"] = "1"
+
     def fresh():
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
         cm.build(sf, model, threads=1, dist=shard, heat=heat)
+        if args.lineal:
+            sf.lib.sf3d_set_use_lineal(1)
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
 
     t0 = time.perf_counter()
@@ -373,7 +379,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone DEM (DATA/DEM/DEM_Ravone.flt), 14 soil layers to 0.95 m"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + f", forcing {args.forcing}, "
+        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone DEM (DATA/DEM/DEM_Ravone.flt), 14 soil layers to 0.95 m"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
                                f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)",
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},

@@ -166,6 +166,7 @@ sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h
     if (c != SF3D_OK) return c;
     M.water = w != 0; M.heat = h != 0; M.solutes = s != 0;
     { const char* ce = getenv("SF3D_COMPAT_STALE_LINK_FLOW"); M.compat = ce && ce[0] == '1'; }
+    { const char* ge = getenv("SF3D_LINEAL_DEVICE_CG"); M.cgArrays = ge && ge[0] == '1'; P.lineal = useLineal && M.cgArrays; }
     if (M.heat) { HF.vapor = true; HF.advection = true; HF.save = saveMode; }        /* :58-65 */
     M.heatVapor = HF.vapor; M.heatAdvection = HF.advection; M.heatSave = HF.save;
     M.N = n; M.ns = ns;
@@ -239,7 +240,17 @@ uint32_t sf3d_set_threads_number(uint32_t n)                        /* soilFluxe
     if (M.solverReady) P.numThreads = n;
     return n;
 }
-void sf3d_set_use_lineal(int v) { if (M.solverReady) useLineal = v != 0; }     /* the library's own Jacobi is always used */
+/* setUseLineal, soilFluxes3D.cpp:367-372.  The third-party liblinealia is not part of the repository and is never loaded; by default the
+ * library keeps its own Jacobi (= the reference with useLineal = false).  With SF3D_LINEAL_DEVICE_CG=1 in the environment a true value
+ * selects the device's Jacobi-preconditioned conjugate gradients for the linear systems (one GPU; parity with linealia is unpinned by
+ * construction - there is no binary to compare with - so it is checked against the Jacobi solution instead, tests/test_gpu_cg.py) */
+void sf3d_set_use_lineal(int v)
+{
+    if (!M.solverReady) return;
+    useLineal = v != 0;
+    const bool want = useLineal && M.cgArrays;
+    if (want != P.lineal) { P.lineal = want; M.ctrlDirty = true; }
+}
 void sf3d_set_lineal_method(int v) { if (M.solverReady) linealMethod = v; }
 
 sf3d_error_t sf3d_set_soil_properties(uint16_t nrSoil, uint8_t nrHorizon, double alpha, double n, double m,

@@ -132,6 +132,12 @@ struct Ctrl {
     /* ---- query results (getTotalWaterContent etc.) ---- */
     double query[2];
     /* ---- quirk-1 compat (SF3D_COMPAT_STALE_LINK_FLOW=1): which assembly k_compat_rows has to mirror into the emulated row storage ---- */
+    /* ---- Jacobi-preconditioned conjugate gradients standing in for the linealia hook (setUseLineal, cpusolver.cpp:608-669) ---- */
+    uint32_t lineal;          /* 1: an approximation's linear system is solved by the k_cg_* kernels instead of Jacobi sweeps */
+    uint32_t cgState;         /* 0 idle, 1 iterating, 2 converged / out of budget: k_cg_finish clamps the surface and hands over to ST_POST */
+    int32_t cgX;              /* pool index of the iterate (a free buffer: Hold may be the same buffer as H) */
+    uint32_t cgPad;
+    double cgRho, cgAlpha, cgBeta, cgBnorm2, cgRes2;
     uint32_t seqCount, seqSweeps[16];   /* Jacobi iterations of the 1st, 2nd, ... approximation of the computeStep in progress (0 for one the Courant check
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
     uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
@@ -269,6 +275,8 @@ struct DevView {
      * diagonal of the row k_assemble has just written UN-normalised (k_compat_rows normalises after the Courant decision, like
      * the reference's separate preconditioning pass) */
     double* compatCv; uint8_t* compatCn; double* compatDiag;
+    /* conjugate gradients (null unless the device CG is enabled): diagonal of the un-normalised rows, residual, direction, A p */
+    double *cgDiag, *cgR, *cgP, *cgQ;
     double *part0, *part1;              /* per-block partials [nb] */
     unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
     unsigned int* gridBar;              /* arrival counter of the persistent step kernel's grid barrier (monotonic) */

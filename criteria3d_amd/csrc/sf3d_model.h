@@ -28,11 +28,13 @@ struct ParamsHost {                    /* SolverParameters, types.h:291-315 (per
     double lvRatio = 4., courantThreshold = 0.5, instabilityFactor = 10.;
     double heatWeightFactor = 0.5;     /* types.h:307 */
     uint32_t numThreads = 1;
+    bool lineal = false;               /* setUseLineal(true) AND SF3D_LINEAL_DEVICE_CG=1: device conjugate gradients instead of Jacobi sweeps */
 };
 
 struct HostModel {
     bool initialized = false, solverReady = false;
     bool water = true, heat = false, solutes = false;
+    bool cgArrays = false;           /* allocate the conjugate-gradient work vectors (SF3D_LINEAL_DEVICE_CG=1 at sf3d_initialize) */
     bool compat = false;             /* SF3D_COMPAT_STALE_LINK_FLOW=1 at sf3d_initialize: reproduce quirk 1's stale-slot reads */
     uint32_t N = 0, ns = 0;
     std::vector<double> x, y, z, size;

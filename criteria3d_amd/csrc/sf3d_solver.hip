@@ -985,6 +985,7 @@ __device__ __forceinline__ double store_row(const DevView& v, sf3d_d2* __restric
     const bool raw = v.compatDiag != nullptr;          /* compat: row stored un-normalised, k_compat_rows scales it after the Courant decision */
     const double inv = raw ? 1.0 : 1.0 / (cdt + sum);  /* (x * 1.0 is exact) */
     if (raw) v.compatDiag[i] = cdt + sum;
+    if (v.cgDiag != nullptr) v.cgDiag[i] = cdt + sum;
     #pragma unroll
     for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
         k[2 * p] = (k[2 * p] * -1.) * inv; k[2 * p + 1] = (k[2 * p + 1] * -1.) * inv;
@@ -1252,6 +1253,133 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_
 {
     if (v.ctrl->stage != ST_APPROX) return;
     body_assemble<FUSED, NT, HEAT, SWEEP0, false>(v);
+}
+
+/* ---- Jacobi-preconditioned conjugate gradients: the device's stand-in for the linealia hook (cpusolver.cpp:608-669) ------------
+ * The reference hands the row-normalised system A~ x = b~ (A~ = D^-1 S, S symmetric: every conductance is computed from both ends
+ * with the same formula) to the third-party library with max_iterations = the Jacobi budget and max_relative_residual_norm =
+ * residualTolerance, clamps the surface heads to the ground afterwards and always reports success.  Conjugate gradients on S with
+ * the preconditioner D are the same iteration written on the normalised rows: z = r~ (the normalised residual), inner products
+ * weighted with the diagonal d that store_row keeps for this purpose.  One iteration = three guarded launches:
+ *   k_cg_matvec   q = A~ p, partial sums of p d q          -> last block: alpha
+ *   k_cg_update   x += alpha p, r~ -= alpha q, sums of d r~^2 and r~^2 -> last block: beta, stopping test (||r~|| / ||b~|| < tol, budget)
+ *   k_cg_dir      p = r~ + beta p
+ * k_cg_init computes the first residual into a free head buffer's companion vectors; k_cg_finish clamps and moves on to ST_POST.
+ * Single GPU.  The iteration count goes into the sweep counter. */
+template <class F>
+__device__ __forceinline__ double cg_row(const DevView& v, const sf3d_d2* __restrict__ A2, uint32_t q, uint32_t i, const double* __restrict__ vec, F self)
+{
+    double a[SF3D_SLOTS]; uint32_t j[SF3D_SLOTS];
+    #pragma unroll
+    for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
+    const ChunkDesc cd = v.cdesc[q];
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) j[s] = (cd.kind[s] != CK_MIXED) ? i + cd.delta[s] : v.lto[(size_t)s * v.N + i];
+    double acc = self(vec[i]);                           /* diagonal of the normalised row = 1 */
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) if (a[s] != 0.) acc += a[s] * vec[j[s]];
+    return acc;
+}
+__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_init(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 0) return;
+    const int nxt = free_buffer(c);
+    const double* __restrict__ x = v.X[c->cur];
+    double* __restrict__ xn = v.X[nxt];
+    const sf3d_d2* __restrict__ A2 = cur_A2(v);
+    double rho = 0., b2 = 0.;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double ax = cg_row(v, A2, q, i, x, [](double s) { return s; });
+        const double bi = v.b[i], r = bi - ax, d = v.cgDiag[i];
+        xn[i] = x[i]; v.cgR[i] = r; v.cgP[i] = r;
+        rho += d * r * r; b2 += bi * bi;
+    }
+    const double s0 = block_sum(rho), s1 = block_sum(b2);
+    if (!arrive_last(v, s0, s1, true)) return;
+    const double R = sum_published(v.part0, gridDim.x), B = sum_published(v.part1, gridDim.x);
+    if (threadIdx.x == 0) {
+        c->cgRho = R; c->cgBnorm2 = B; c->cgX = nxt; c->iter = 0;
+        c->cgState = (!(B > 0.) || !(R > 0.)) ? 2u : 1u;      /* b = 0 or an exact start: nothing to iterate */
+    }
+}
+__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_matvec(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
+    const sf3d_d2* __restrict__ A2 = cur_A2(v);
+    double pq = 0.;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        const double qi = cg_row(v, A2, q, i, v.cgP, [](double s) { return s; });
+        v.cgQ[i] = qi;
+        pq += v.cgP[i] * v.cgDiag[i] * qi;
+    }
+    const double s0 = block_sum(pq);
+    if (!arrive_last(v, s0, 0., false)) return;
+    const double PQ = sum_published(v.part0, gridDim.x);
+    if (threadIdx.x == 0) {
+        if (PQ > 0.) c->cgAlpha = c->cgRho / PQ;
+        else { c->cgAlpha = 0.; c->cgState = 2; }         /* breakdown (not positive definite, or NaN): stop with what we have */
+    }
+}
+__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_update(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
+    double* __restrict__ x = v.X[c->cgX];
+    const double alpha = c->cgAlpha;
+    double rho = 0., r2 = 0.;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        x[i] += alpha * v.cgP[i];
+        const double r = v.cgR[i] - alpha * v.cgQ[i];
+        v.cgR[i] = r;
+        rho += v.cgDiag[i] * r * r; r2 += r * r;
+    }
+    const double s0 = block_sum(rho), s1 = block_sum(r2);
+    if (!arrive_last(v, s0, s1, true)) return;
+    const double R = sum_published(v.part0, gridDim.x), R2 = sum_published(v.part1, gridDim.x);
+    if (threadIdx.x == 0) {
+        c->iter++; c->counters[3]++;
+        c->cgRes2 = R2; c->lastNorm = sqrt(R2 / c->cgBnorm2);
+        c->cgBeta = R / c->cgRho; c->cgRho = R;
+        if (!(R2 > c->residualTolerance * c->residualTolerance * c->cgBnorm2) || c->iter >= c->iterBudget || !(R > 0.)) c->cgState = 2;
+    }
+}
+__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_dir(DevView v)
+{
+    const Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
+    const double beta = c->cgBeta;
+    FOR_EACH_CHUNK(v) {
+        const uint32_t i = q * SF3D_CHUNK + lane_;
+        if (i >= v.N) continue;
+        v.cgP[i] = v.cgR[i] + beta * v.cgP[i];
+    }
+}
+/* linealSolver's tail (cpusolver.cpp:657-667): surface heads not below the ground; the solve always counts as valid */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_finish(DevView v)
+{
+    Ctrl* c = v.ctrl;
+    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 2) return;
+    double* __restrict__ x = v.X[c->cgX];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < v.ns; i += gridDim.x * blockDim.x) {
+        const double zi = v.z[i];
+        if (x[i] - zi < 0.) x[i] = zi;
+    }
+    __syncthreads();
+    if (!arrive_last(v, 0., 0., false)) return;
+    if (threadIdx.x == 0) {
+        c->cur = c->cgX; c->cgState = 0; c->linearValid = 1;
+        if (c->seqCount < 16u) c->seqSweeps[c->seqCount] = c->iter;
+        c->seqCount++;
+        c->stage = ST_POST;
+    }
 }
 
 /* quirk-1 compat only.  Mirrors the assembly that has just been decided into the emulated row storage of the reference
@@ -2092,6 +2220,7 @@ static void fill_params(Ctrl& c, const ParamsHost& p)
     c.courantThreshold = p.courantThreshold; c.instabilityFactor = p.instabilityFactor;
     c.maxApprox = p.maxApprox; c.maxIter = p.maxIter; c.wrc = p.wrc; c.meanType = p.meanType;
     c.dtCurr = p.dtCurr;
+    c.lineal = p.lineal ? 1u : 0u;
 }
 
 sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
@@ -2515,6 +2644,10 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             HIP_TRY(dev_alloc(I.allocs, v.compatCv, (size_t)N * (SF3D_SLOTS + 2))); HIP_TRY(hipMemset(v.compatCv, 0, (size_t)N * (SF3D_SLOTS + 2) * 8));
             HIP_TRY(dev_alloc(I.allocs, v.compatCn, N)); HIP_TRY(hipMemset(v.compatCn, 0, N));
             HIP_TRY(dev_alloc(I.allocs, v.compatDiag, N)); HIP_TRY(hipMemset(v.compatDiag, 0, (size_t)N * 8));
+        }
+        if (m.cgArrays && world_ == 1) {      /* device conjugate gradients (SF3D_LINEAL_DEVICE_CG=1) */
+            HIP_TRY(dev_alloc(I.allocs, v.cgDiag, N)); HIP_TRY(dev_alloc(I.allocs, v.cgR, N)); HIP_TRY(dev_alloc(I.allocs, v.cgP, N)); HIP_TRY(dev_alloc(I.allocs, v.cgQ, N));
+            HIP_TRY(hipMemset(v.cgDiag, 0, (size_t)N * 8)); HIP_TRY(hipMemset(v.cgR, 0, (size_t)N * 8)); HIP_TRY(hipMemset(v.cgP, 0, (size_t)N * 8)); HIP_TRY(hipMemset(v.cgQ, 0, (size_t)N * 8));
         }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
@@ -2988,7 +3121,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
     if (I.fuseFirstSweep < 0) { const char* e = getenv("SF3D_FUSE_FIRST_SWEEP"); I.fuseFirstSweep = (e && e[0] == '1') ? 1 : 0; }   /* measured slower: off */
     const bool compat = v.compatCv != nullptr;   /* quirk-1 emulation: rows are stored raw and normalised by k_compat_rows after the Courant decision */
-    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat && v.nAsmGen == v.nList;      /* k_assemble also does the first Jacobi iteration */
+    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat && v.nAsmGen == v.nList && !(p.lineal && v.cgDiag != nullptr);      /* k_assemble also does the first Jacobi iteration */
     /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
      * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
      * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
@@ -3009,7 +3142,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     if (heatOn && multi) I.useFused = 1;       /* the sharded heat step exists only in the fused-exchange form */
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
-    const bool pairOn = fused && I.pairBlocks != 0 && !fuse0;   /* k_sweep_pair instead of k_sweep */
+    const bool linealOn = p.lineal && v.cgDiag != nullptr && !multi && I.useFused;     /* the linealia stand-in: device conjugate gradients */
+    const bool pairOn = fused && I.pairBlocks != 0 && !fuse0 && !linealOn;   /* k_sweep_pair instead of k_sweep */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
 
@@ -3061,7 +3195,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
         }
     }
-    const bool persistentStep = I.persistent == 1 && !timedStep && I.timing != 1;
+    const bool persistentStep = I.persistent == 1 && !timedStep && I.timing != 1 && !linealOn;
     {   /* this step assembles into the copy of the matrix that the step before the last one used (k_step_begin flips Ctrl::aBuf): the
          * link flow sums that read it - queued two steps ago on the second stream - must be done; so must they before this step's
          * sweeps reuse the head buffer they read.  The sums of the LAST step run next to this whole step - unless this step adds its
@@ -3125,6 +3259,14 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
         }
         if (withHead && compat) hipLaunchKernelGGL(k_compat_rows, grid, block, 0, st, v);
+        if (linealOn) {     /* conjugate gradients instead of Jacobi sweeps: `chunk` counts Jacobi sweeps, CG needs far fewer iterations */
+            hipLaunchKernelGGL(k_cg_init, grid, block, 0, st, v);
+            for (uint32_t k = 0; k < chunk; ++k) {
+                timed(KID_SWEEP, [&] { hipLaunchKernelGGL(k_cg_matvec, grid, block, 0, st, v); hipLaunchKernelGGL(k_cg_update, grid, block, 0, st, v);
+                                       hipLaunchKernelGGL(k_cg_dir, grid, block, 0, st, v); });
+            }
+            hipLaunchKernelGGL(k_cg_finish, grid, block, 0, st, v);
+        } else
         if (pairOn) {      /* two Jacobi iterations per launch (regular grid, one GPU): ceil(chunk / 2) launches */
             const dim3 pgr(I.pairBlocks), pbl((v.pair.W + 1) * 64);
             for (uint32_t k = 0; k < (chunk + 1) / 2; ++k)
@@ -3181,7 +3323,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     };
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
         if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
