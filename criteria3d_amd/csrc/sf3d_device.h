@@ -180,6 +180,14 @@ struct DistView {
     /* [10][N]: where the value of a FOREIGN neighbour arrives in my window (SF3D_FSRC_NONE for local neighbours); read only
      * in chunks whose descriptor is flagged (ChunkDesc::pad0): the sweeps take foreign neighbours straight from the payload */
     const uint32_t* fsrc;
+    /* SF3D_EXCHANGE=rccl (or the automatic fall-back when the windows fail their self-check): halos travel as paired ncclSend /
+     * ncclRecv of packed buffers and the partial sums as an ncclAllGather, all queued by the host between the kernels (the form
+     * SURVEY.md 8e sketches); the decision kernels then combine `gathered` in rank order exactly like the window mailboxes */
+    int32_t rccl;
+    double* mine;                        /* [3] this rank's partial sums (k_local_reduce) */
+    const double* gathered;              /* [world][3] after ncclAllGather */
+    double* sendBuf[SF3D_MAX_RANKS];     /* per peer: [2 fields][sendCount] packed halo values */
+    const double* recvBuf[SF3D_MAX_RANKS];
 };
 /* payload layout per (receiver, source p): [parity 0/1][field][count] doubles at offset off[p];
  * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate

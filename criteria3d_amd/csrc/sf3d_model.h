@@ -91,6 +91,7 @@ struct DistBlob {
     uint32_t world, rank;
     uint64_t nodes;
     uint32_t generation, pad;       /* export count of the rank; rank 0's value stamps the self-check token of a connect */
+    unsigned char ncclId[128];     /* rank 0: ncclUniqueId of the run's RCCL communicator (all zero when RCCL is not available) */
     char pciBusId[32];             /* which physical GPU the rank runs on (start-up self-check: distinct, peer-reachable devices) */
 };
 

@@ -21,6 +21,8 @@
  *     once per approximation instead of once per kernel.
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      /* types only: the library is dlopen'ed when a multi-GPU run asks for the RCCL exchange */
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -259,6 +261,20 @@ __device__ __forceinline__ double dtheta_dh(const SoilDev& s, double H, double H
 __device__ __forceinline__ bool dist_allgather(const DevView& v, Ctrl* c, double (&vals)[3], int op)
 {
     if (v.world <= 1) return true;
+    if (v.dist->rccl) {        /* the host queued k_local_reduce + ncclAllGather before this kernel: combine in rank order */
+        __shared__ double shR[3];
+        if (threadIdx.x == 0) {
+            const double* g = v.dist->gathered;
+            double acc[3] = {g[0], g[1], g[2]};
+            for (int p = 1; p < v.world; ++p)
+                for (int k = 0; k < 3; ++k) { const double x = g[3 * p + k]; acc[k] = op ? dmax(acc[k], x) : acc[k] + x; }
+            shR[0] = acc[0]; shR[1] = acc[1]; shR[2] = acc[2];
+            c->epoch = c->epoch + 1;
+        }
+        __syncthreads();
+        vals[0] = shR[0]; vals[1] = shR[1]; vals[2] = shR[2];
+        return true;
+    }
     __shared__ double shIn[SF3D_MAX_RANKS][3];
     __shared__ double sh[3];
     __shared__ int shOk;
@@ -313,8 +329,13 @@ __device__ __forceinline__ void dist_unpack(const DevView& v, uint32_t par, int 
     for (int p = 0; p < v.world; ++p) {
         const uint32_t cnt = d->recvCount[p];
         if (cnt == 0) continue;
-        const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         const uint32_t* idx = d->recvIdx[p];
+        if (d->rccl) {             /* packed buffer filled by ncclRecv: slot 0 = the sweep iterate or K, slot 1 = waterFlow */
+            const double* rb = d->recvBuf[p] + (size_t)(field == DF_FLOW ? 1 : 0) * cnt;
+            for (uint32_t k = threadIdx.x; k < cnt; k += SF3D_BLOCK) dst[idx[k]] = rb[k];
+            continue;
+        }
+        const double* src = d->payload[v.rank] + d->recvOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         for (uint32_t k0 = threadIdx.x; k0 < cnt; k0 += SF3D_BLOCK * U) {
             double val[U]; uint32_t id[U];
             #pragma unroll
@@ -339,8 +360,13 @@ __device__ __forceinline__ void dist_push(const DevView& v, uint32_t par, int fi
     for (int p = 0; p < v.world; ++p) {
         const uint32_t cnt = d->sendCount[p];
         if (cnt == 0) continue;
-        double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         const uint32_t* idx = d->sendIdx[p];
+        if (d->rccl) {             /* pack for ncclSend */
+            double* sb = d->sendBuf[p] + (size_t)(field == DF_FLOW ? 1 : 0) * cnt;
+            for (uint32_t k = tid; k < cnt; k += nth) sb[k] = src[idx[k]];
+            continue;
+        }
+        double* dst = d->payload[p] + d->sendOff[p] + (size_t)(par * SF3D_DIST_FIELDS + field) * cnt;
         for (uint32_t k = tid; k < cnt; k += nth) SYS_STORE(&dst[k], src[idx[k]]);
     }
 }
@@ -373,6 +399,17 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sync_kf(DevView v)
     if (!dist_allgather(v, c, vals, 0)) return;
     dist_unpack(v, par, DF_K, v.K);
     dist_unpack(v, par, DF_FLOW, v.flow);
+}
+
+/* SF3D_EXCHANGE=rccl: this rank's partial sums for the ncclAllGather the host queues next.  what: 0 = sum of part0[nb] (sweep norm,
+ * storage query), 1 = maximum of part0[nbSurf] (Courant), 2 = sums of part0[nb] and part1[nb] (balance); the same reductions, in the
+ * same order, as the decision kernel that follows would make for itself */
+__global__ void __launch_bounds__(SF3D_BLOCK) k_local_reduce(DevView v, int what)
+{
+    double a = 0., b = 0.;
+    if (what == 1) a = reduce_partials_max(v.part0, v.nbSurf);
+    else { a = reduce_partials_sum(v.part0, v.nb); if (what == 2) b = reduce_partials_sum(v.part1, v.nb); }
+    if (threadIdx.x == 0) { double* m = v.dist->mine; m[0] = a; m[1] = b; m[2] = 0.; }
 }
 
 /* ---- last-block hand-off inside a launch ---------------------------------------------------
@@ -2129,6 +2166,42 @@ struct DeviceSolver::Impl {
     DistView hostDist{};
     DistView* devDist = nullptr;
     uint32_t pushBlocks = 0;
+    /* RCCL exchange (SF3D_EXCHANGE=rccl, or agreed fall-back when the windows fail): resolved with dlsym, no link-time dependency */
+    void* rcclLib = nullptr; ncclComm_t comm = nullptr; bool rcclMode = false;
+    ncclResult_t (*pGetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*pCommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*pCommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*pSend)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pRecv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pAllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*pGroupStart)() = nullptr; ncclResult_t (*pGroupEnd)() = nullptr;
+    double *rcclMine = nullptr, *rcclGathered = nullptr;
+    bool load_rccl()
+    {
+        if (pAllGather) return true;
+        if (!rcclLib) rcclLib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!rcclLib) rcclLib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!rcclLib) return false;
+        #define SF3D_SYM(ptr, name) ptr = reinterpret_cast<decltype(ptr)>(dlsym(rcclLib, name)); if (!ptr) return false
+        SF3D_SYM(pGetUniqueId, "ncclGetUniqueId"); SF3D_SYM(pCommInitRank, "ncclCommInitRank"); SF3D_SYM(pCommDestroy, "ncclCommDestroy");
+        SF3D_SYM(pSend, "ncclSend"); SF3D_SYM(pRecv, "ncclRecv"); SF3D_SYM(pAllReduce, "ncclAllReduce");
+        SF3D_SYM(pGroupStart, "ncclGroupStart"); SF3D_SYM(pGroupEnd, "ncclGroupEnd"); SF3D_SYM(pAllGather, "ncclAllGather");
+        #undef SF3D_SYM
+        return true;
+    }
+    /* halo of one or two fields to and from every neighbour, then (optionally) the all-gather of the partial sums */
+    void rccl_halo(hipStream_t st, int fields)
+    {
+        pGroupStart();
+        for (int p = 0; p < hostDist.world; ++p) {
+            if (p == hostDist.rank) continue;
+            if (hostDist.sendCount[p]) pSend(hostDist.sendBuf[p], (size_t)hostDist.sendCount[p] * fields, ncclDouble, p, comm, st);
+            if (hostDist.recvCount[p]) pRecv(const_cast<double*>(hostDist.recvBuf[p]), (size_t)hostDist.recvCount[p] * fields, ncclDouble, p, comm, st);
+        }
+        pGroupEnd();
+    }
+    void rccl_gather(hipStream_t st) { pAllGather(rcclMine, rcclGathered, 3, ncclDouble, comm, st); }
     uint32_t connectGen = 0;               /* token of the window self-check */
     bool warnedShared = false;
     /* timing */
@@ -2184,6 +2257,8 @@ sf3d_error_t DeviceSolver::release()
     I.graphs.clear();
     for (void* p : I.allocs) hipFree(p);
     I.allocs.clear();
+    if (I.comm && I.pCommDestroy) { I.pCommDestroy(I.comm); I.comm = nullptr; }
+    I.rcclMode = false; I.rcclMine = I.rcclGathered = nullptr;
     for (void* p : I.peerMaps) hipIpcCloseMemHandle(p);
     I.peerMaps.clear();
     if (I.window) { hipFree(I.window); I.window = nullptr; }
@@ -2933,6 +3008,12 @@ sf3d_error_t DeviceSolver::dist_export(HostModel& m, const ParamsHost& p, DistBl
     for (int r = 0; r < world_; ++r) { out->recvOff[r] = I.hostDist.recvOff[r]; out->recvCount[r] = I.hostDist.recvCount[r]; }
     if (hipDeviceGetPCIBusId(out->pciBusId, (int)sizeof(out->pciBusId), I.device) != hipSuccess) out->pciBusId[0] = 0;
     out->generation = ++I.connectGen;
+    {   const char* xe = getenv("SF3D_EXCHANGE");
+        if (rank_ == 0 && !(xe && std::strcmp(xe, "ipc") == 0) && I.load_rccl()) {
+            ncclUniqueId id;
+            if (I.pGetUniqueId(&id) == ncclSuccess) { static_assert(sizeof(id) <= sizeof(out->ncclId), "ncclUniqueId size"); std::memcpy(out->ncclId, &id, sizeof(id)); }
+        }
+    }
     return SF3D_OK;
 }
 
@@ -2942,7 +3023,9 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
     if (!built_) { snprintf(err_, sizeof(err_), "dist_connect before dist_export"); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     HIP_TRY(hipSetDevice(I.device));
+    static_assert(SF3D_MAX_RANKS >= 8, "a node has eight MI355X");
     DistView& d = I.hostDist;
+    char why[200] = {0};                  /* why the window exchange is not usable on this rank (empty: it is) */
     for (int r = 0; r < world_; ++r) {
         const DistBlob& b = all[r];
         if ((int)b.world != world_ || (int)b.rank != r || b.nodes != I.N) { snprintf(err_, sizeof(err_), "dist_connect: blob %d does not match (world %u rank %u nodes %llu)", r, b.world, b.rank, (unsigned long long)b.nodes); return SF3D_PARAMETER_ERROR; }
@@ -2953,31 +3036,52 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
         hipIpcMemHandle_t h;
         std::memcpy(&h, b.ipcHandle, sizeof(h));
         void* ptr = nullptr;
-        HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        const hipError_t oe = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (oe != hipSuccess) {
+            (void)hipGetLastError();
+            if (!why[0]) snprintf(why, sizeof(why), "hipIpcOpenMemHandle of rank %d's window failed: %s", r, hipGetErrorString(oe));
+            d.win[r] = I.window; d.payload[r] = d.payload[rank_];        /* never dereferenced in the RCCL mode; keeps the view well-formed */
+            continue;
+        }
         I.peerMaps.push_back(ptr);
         d.win[r] = static_cast<DistWindow*>(ptr);
         d.payload[r] = reinterpret_cast<double*>(static_cast<char*>(ptr) + sizeof(DistWindow));
     }
+    /* ---- which physical GPUs: distinct?  peer-reachable? ---- */
+    const bool shareOk = getenv("SF3D_BENCH_SHARE_GPU") && getenv("SF3D_BENCH_SHARE_GPU")[0] == '1';
+    const char* mine = all[rank_].pciBusId;
+    bool distinct = true;
+    for (int a = 0; a < world_; ++a)
+        for (int r = a + 1; r < world_; ++r)
+            if (!all[a].pciBusId[0] || !all[r].pciBusId[0] || std::strncmp(all[a].pciBusId, all[r].pciBusId, sizeof(all[r].pciBusId)) == 0) distinct = false;
+    for (int r = 0; r < world_; ++r) {
+        if (r == rank_ || !mine[0] || !all[r].pciBusId[0]) continue;
+        if (std::strncmp(mine, all[r].pciBusId, sizeof(all[r].pciBusId)) == 0) {
+            if (!shareOk && !I.warnedShared) { fprintf(stderr, "sf3d: warning: ranks %d and %d run on the same GPU (%s): one process per GPU is the intended layout (set LOCAL_RANK / sf3d_set_device)\n", rank_, r, mine); I.warnedShared = true; }
+            continue;
+        }
+        int peerDev = -1, can = 1;
+        if (hipDeviceGetByPCIBusId(&peerDev, all[r].pciBusId) == hipSuccess && peerDev >= 0 && peerDev != I.device
+            && hipDeviceCanAccessPeer(&can, I.device, peerDev) == hipSuccess && !can && !why[0])
+            snprintf(why, sizeof(why), "GPU %s (rank %d) cannot access GPU %s (rank %d) peer-to-peer", mine, rank_, all[r].pciBusId, r);
+        (void)hipGetLastError();     /* a peer that is not visible to this process (one device per process) is checked by the ping alone */
+    }
+    /* ---- RCCL communicator: only with one GPU per rank (RCCL refuses two ranks on a device) and an id from rank 0 ---- */
+    const char* xe = getenv("SF3D_EXCHANGE");
+    const bool forceRccl = xe && std::strcmp(xe, "rccl") == 0, forbidRccl = xe && std::strcmp(xe, "ipc") == 0;
+    bool haveId = false;
+    for (size_t k = 0; k < sizeof(all[0].ncclId); ++k) if (all[0].ncclId[k]) haveId = true;
+    bool rcclOk = false;
+    if (!forbidRccl && distinct && haveId && I.load_rccl()) {
+        ncclUniqueId id;
+        std::memcpy(&id, all[0].ncclId, sizeof(id));
+        if (I.pCommInitRank(&I.comm, world_, id, rank_) == ncclSuccess) rcclOk = true; else I.comm = nullptr;
+    }
+    if (forceRccl && !rcclOk) { snprintf(err_, sizeof(err_), "SF3D_EXCHANGE=rccl: no RCCL communicator (librccl not loadable, or ranks share a GPU: RCCL needs one GPU per rank)"); return SF3D_SOLVER_ERROR; }
     HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
     I.v.dist = I.devDist;
-    {   /* start-up self-check: distinct, peer-reachable devices, and one value through every window both ways */
-        static_assert(SF3D_MAX_RANKS >= 8, "a node has eight MI355X");
-        const bool shareOk = getenv("SF3D_BENCH_SHARE_GPU") && getenv("SF3D_BENCH_SHARE_GPU")[0] == '1';
-        const char* mine = all[rank_].pciBusId;
-        for (int r = 0; r < world_; ++r) {
-            if (r == rank_ || !mine[0] || !all[r].pciBusId[0]) continue;
-            if (std::strncmp(mine, all[r].pciBusId, sizeof(all[r].pciBusId)) == 0) {
-                if (!shareOk && !I.warnedShared) { fprintf(stderr, "sf3d: warning: ranks %d and %d run on the same GPU (%s): one process per GPU is the intended layout (set LOCAL_RANK / sf3d_set_device)\n", rank_, r, mine); I.warnedShared = true; }
-                continue;
-            }
-            int peerDev = -1, can = 1;
-            if (hipDeviceGetByPCIBusId(&peerDev, all[r].pciBusId) == hipSuccess && peerDev >= 0 && peerDev != I.device
-                && hipDeviceCanAccessPeer(&can, I.device, peerDev) == hipSuccess && !can) {
-                snprintf(err_, sizeof(err_), "dist_connect: GPU %s (rank %d) cannot access GPU %s (rank %d) peer-to-peer: the halo exchange needs P2P over xGMI/PCIe", mine, rank_, all[r].pciBusId, r);
-                return SF3D_SOLVER_ERROR;
-            }
-            (void)hipGetLastError();     /* a peer that is not visible to this process (one device per process) is checked by the ping alone */
-        }
+    /* ---- one value through every window, both ways, within a bound ---- */
+    if (!why[0] && !forceRccl) {
         double timeoutS = 5.0;
         if (const char* te = getenv("SF3D_DIST_PING_TIMEOUT_S")) { const double t = atof(te); if (t > 0) timeoutS = t; }
         int* dres = nullptr;
@@ -2990,12 +3094,40 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
         if (pe == hipSuccess) pe = hipStreamSynchronize(I.stream);
         (void)hipFree(dres);
         if (pe != hipSuccess) { snprintf(err_, sizeof(err_), "dist_connect: window self-check failed: %s (cross-device IPC mapping unusable?)", hipGetErrorString(pe)); fatal_ = true; return SF3D_SOLVER_ERROR; }
-        int pos = 0; char who[128] = {0};
+        int pos = 0; char who[96] = {0};
         for (int r = 0; r < world_; ++r) if (!res[r]) pos += snprintf(who + pos, sizeof(who) - pos, " %d", r);
-        if (pos) {
-            snprintf(err_, sizeof(err_), "dist_connect: rank %d got no answer through the window of rank(s)%s within %.0f s (peer not connected, or device-initiated stores do not cross GPUs here)", rank_, who, timeoutS);
-            return SF3D_SOLVER_ERROR;
+        if (pos) snprintf(why, sizeof(why), "no answer through the window of rank(s)%s within %.0f s (peer not connected, or device-initiated stores do not cross GPUs here)", who, timeoutS);
+    }
+    /* ---- agree on the exchange: every rank must pick the same one ---- */
+    bool useRccl = forceRccl;
+    if (rcclOk) {
+        HIP_TRY(dev_alloc(I.allocs, I.rcclMine, 4)); HIP_TRY(dev_alloc(I.allocs, I.rcclGathered, (size_t)3 * world_ + 1));
+        if (!forceRccl) {
+            const double flag = why[0] ? 0. : 1.;
+            double agreed = 0.;
+            HIP_TRY(hipMemcpy(I.rcclMine, &flag, sizeof(double), hipMemcpyHostToDevice));
+            if (I.pAllReduce(I.rcclMine, I.rcclMine + 1, 1, ncclDouble, ncclMin, I.comm, I.stream) != ncclSuccess) { snprintf(err_, sizeof(err_), "dist_connect: ncclAllReduce failed"); return SF3D_SOLVER_ERROR; }
+            HIP_TRY(hipMemcpyAsync(&agreed, I.rcclMine + 1, sizeof(double), hipMemcpyDeviceToHost, I.stream));
+            HIP_TRY(hipStreamSynchronize(I.stream));
+            useRccl = agreed < 0.5;
         }
+    } else if (why[0]) {
+        snprintf(err_, sizeof(err_), "dist_connect: rank %d: %.180s - and no RCCL communicator to fall back on", rank_, why);
+        return SF3D_SOLVER_ERROR;
+    }
+    if (useRccl) {
+        if (I.v.heat.on) { snprintf(err_, sizeof(err_), "the RCCL exchange does not carry the coupled heat step (window exchange only)"); return SF3D_SOLVER_ERROR; }
+        d.rccl = 1; d.mine = I.rcclMine; d.gathered = I.rcclGathered;
+        for (int r = 0; r < world_; ++r) {
+            double *sb = nullptr, *rb = nullptr;
+            HIP_TRY(dev_alloc(I.allocs, sb, (size_t)d.sendCount[r] * 2)); HIP_TRY(dev_alloc(I.allocs, rb, (size_t)d.recvCount[r] * 2));
+            d.sendBuf[r] = sb; d.recvBuf[r] = rb;
+        }
+        I.v.haloDirect = 0;                  /* sweeps read the halo from the arrays the unpack filled, not from a window */
+        I.useFused = 0;                      /* the exchange sits BETWEEN the kernels: separate decision kernels */
+        I.rcclMode = true;
+        if (rank_ == 0) fprintf(stderr, "sf3d: multi-GPU exchange over RCCL (ncclSend/ncclRecv halos + ncclAllGather of the partial sums)%s%s\n", why[0] ? ": " : "", why);
+        HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
     }
     connected_ = true;
     return SF3D_OK;
@@ -3008,6 +3140,7 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
     if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect"); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     hipLaunchKernelGGL(k_storage, dim3(I.v.nb), dim3(SF3D_BLOCK), 0, I.stream, I.v);
+    if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v, 0); I.rccl_gather(I.stream); }
     hipLaunchKernelGGL(k_decide_query, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(I.hostCtrl, I.v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, I.stream));
@@ -3235,6 +3368,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             else timed(KID_PROPS, [&] { hipLaunchKernelGGL((k_props<0, false>), propsGrid, block, 0, st, v); });
             if (multi && !fusedMulti) {
                 hipLaunchKernelGGL(k_push_kf, pgrid, block, 0, st, v);
+                if (I.rcclMode) I.rccl_halo(st, 2);
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
     };
@@ -3255,6 +3389,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
                 timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 1); I.rccl_gather(st); }
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
         }
@@ -3286,11 +3421,13 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (fusedMulti) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<2, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<2, false>), grid, block, 0, st, v); }); continue; }
             timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<0, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<0, false>), grid, block, 0, st, v); });
             if (multi) hipLaunchKernelGGL(k_push_x, pgrid, block, 0, st, v);
+            if (I.rcclMode) { I.rccl_halo(st, 1); hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 0); I.rccl_gather(st); }
             hipLaunchKernelGGL(k_decide_sweep, one, block, 0, st, v);
         }
         if (I.useFused) { timed(KID_POST, [&] { hipLaunchKernelGGL(k_post<true>, grid, block, 0, st, v); }); if (multi && v.haloDirect) hipLaunchKernelGGL(k_halo_copy<1>, pgrid, block, 0, st, v); }
         else {
             timed(KID_POST, [&] { hipLaunchKernelGGL(k_post<false>, grid, block, 0, st, v); });
+            if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 2); I.rccl_gather(st); }
             hipLaunchKernelGGL(k_decide_balance, one, block, 0, st, v);
         }
         if (withTail) {     /* restore-best and the flow sums of the accepted step: once per poll group */
@@ -3298,6 +3435,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             else if (I.useFused) timed(KID_RESTORE, [&] { hipLaunchKernelGGL((k_restore<true, false>), grid, block, 0, st, v); });
             else {
                 timed(KID_RESTORE, [&] { if (heatOn) hipLaunchKernelGGL((k_restore<false, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_restore<false, false>), grid, block, 0, st, v); });
+                if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 2); I.rccl_gather(st); }
                 hipLaunchKernelGGL(k_decide_restore, one, block, 0, st, v);
             }
             if (overlap) hipLaunchKernelGGL(k_accept_boundary, grid, block, 0, st, v);
@@ -3322,7 +3460,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         return chunk;
     };
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
-        if (!I.useGraphs || timedStep) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }
+        if (!I.useGraphs || timedStep || I.rcclMode) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }   /* (RCCL calls are queued eagerly) */
         const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
