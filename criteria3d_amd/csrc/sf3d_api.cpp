@@ -755,6 +755,13 @@ sf3d_error_t sf3d_dist_connect(const void* blobs)
     if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_connect: %s\n", dev().last_error());
     return e;
 }
+int sf3d_dist_status(void) { return dev().dist_status(); }
+sf3d_error_t sf3d_dist_finalize(int use_rccl)
+{
+    sf3d_error_t e = dev().dist_finalize(use_rccl != 0);
+    if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_finalize: %s\n", dev().last_error());
+    return e;
+}
 /* partition queries are host logic: they work without a device */
 sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* out)
 {

@@ -127,6 +127,8 @@ public:
     sf3d_error_t dist_prepare(int rank, int world);
     sf3d_error_t dist_export(HostModel& m, const ParamsHost& p, DistBlob* out);
     sf3d_error_t dist_connect(const DistBlob* all);
+    int dist_status() const { return distStatus_; }
+    sf3d_error_t dist_finalize(bool useRccl);
     int world() const { return world_; }
     int rank() const { return rank_; }
     /* instrumentation */
@@ -145,6 +147,8 @@ private:
     int world_ = 1, rank_ = 0;
     bool connected_ = false;
     bool fatal_ = false;
+    int distStatus_ = 0;             /* after dist_connect: 0 the windows passed their self-check, 1 they did not / RCCL was asked for */
+    char distWhy_[200] = {0};
     char err_[256] = {0};
     friend struct Impl;
 };

@@ -2177,6 +2177,7 @@ struct DeviceSolver::Impl {
     ncclResult_t (*pAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*pGroupStart)() = nullptr; ncclResult_t (*pGroupEnd)() = nullptr;
     double *rcclMine = nullptr, *rcclGathered = nullptr;
+    bool rcclDistinct = false; unsigned char rcclId[128] = {0};
     bool load_rccl()
     {
         if (pAllGather) return true;
@@ -3066,18 +3067,8 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
             snprintf(why, sizeof(why), "GPU %s (rank %d) cannot access GPU %s (rank %d) peer-to-peer", mine, rank_, all[r].pciBusId, r);
         (void)hipGetLastError();     /* a peer that is not visible to this process (one device per process) is checked by the ping alone */
     }
-    /* ---- RCCL communicator: only with one GPU per rank (RCCL refuses two ranks on a device) and an id from rank 0 ---- */
     const char* xe = getenv("SF3D_EXCHANGE");
-    const bool forceRccl = xe && std::strcmp(xe, "rccl") == 0, forbidRccl = xe && std::strcmp(xe, "ipc") == 0;
-    bool haveId = false;
-    for (size_t k = 0; k < sizeof(all[0].ncclId); ++k) if (all[0].ncclId[k]) haveId = true;
-    bool rcclOk = false;
-    if (!forbidRccl && distinct && haveId && I.load_rccl()) {
-        ncclUniqueId id;
-        std::memcpy(&id, all[0].ncclId, sizeof(id));
-        if (I.pCommInitRank(&I.comm, world_, id, rank_) == ncclSuccess) rcclOk = true; else I.comm = nullptr;
-    }
-    if (forceRccl && !rcclOk) { snprintf(err_, sizeof(err_), "SF3D_EXCHANGE=rccl: no RCCL communicator (librccl not loadable, or ranks share a GPU: RCCL needs one GPU per rank)"); return SF3D_SOLVER_ERROR; }
+    const bool forceRccl = xe && std::strcmp(xe, "rccl") == 0;
     HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
     I.v.dist = I.devDist;
     /* ---- one value through every window, both ways, within a bound ---- */
@@ -3098,37 +3089,52 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
         for (int r = 0; r < world_; ++r) if (!res[r]) pos += snprintf(who + pos, sizeof(who) - pos, " %d", r);
         if (pos) snprintf(why, sizeof(why), "no answer through the window of rank(s)%s within %.0f s (peer not connected, or device-initiated stores do not cross GPUs here)", who, timeoutS);
     }
-    /* ---- agree on the exchange: every rank must pick the same one ---- */
-    bool useRccl = forceRccl;
-    if (rcclOk) {
-        HIP_TRY(dev_alloc(I.allocs, I.rcclMine, 4)); HIP_TRY(dev_alloc(I.allocs, I.rcclGathered, (size_t)3 * world_ + 1));
-        if (!forceRccl) {
-            const double flag = why[0] ? 0. : 1.;
-            double agreed = 0.;
-            HIP_TRY(hipMemcpy(I.rcclMine, &flag, sizeof(double), hipMemcpyHostToDevice));
-            if (I.pAllReduce(I.rcclMine, I.rcclMine + 1, 1, ncclDouble, ncclMin, I.comm, I.stream) != ncclSuccess) { snprintf(err_, sizeof(err_), "dist_connect: ncclAllReduce failed"); return SF3D_SOLVER_ERROR; }
-            HIP_TRY(hipMemcpyAsync(&agreed, I.rcclMine + 1, sizeof(double), hipMemcpyDeviceToHost, I.stream));
-            HIP_TRY(hipStreamSynchronize(I.stream));
-            useRccl = agreed < 0.5;
-        }
-    } else if (why[0]) {
-        snprintf(err_, sizeof(err_), "dist_connect: rank %d: %.180s - and no RCCL communicator to fall back on", rank_, why);
+    /* what this rank found; the launcher gathers the ranks' findings and calls dist_finalize with the common decision */
+    distStatus_ = (why[0] || forceRccl) ? 1 : 0;
+    std::snprintf(distWhy_, sizeof(distWhy_), "%s", forceRccl ? "SF3D_EXCHANGE=rccl" : why);
+    I.rcclDistinct = distinct;
+    std::memcpy(I.rcclId, all[0].ncclId, sizeof(I.rcclId));
+    connected_ = distStatus_ == 0;        /* a launcher that never calls dist_finalize gets the windows if they work */
+    return SF3D_OK;
+}
+
+/* the common decision of all ranks: keep the windows (all passed) or exchange over RCCL (some rank's did not, or SF3D_EXCHANGE=rccl) */
+sf3d_error_t DeviceSolver::dist_finalize(bool useRccl)
+{
+    if (world_ == 1) { connected_ = true; return SF3D_OK; }
+    if (!built_ || !impl_->v.dist) { snprintf(err_, sizeof(err_), "dist_finalize before dist_connect"); return SF3D_SOLVER_ERROR; }
+    Impl& I = *impl_;
+    if (!useRccl) {
+        if (distStatus_ != 0) { snprintf(err_, sizeof(err_), "dist_finalize(windows), but rank %d: %.160s", rank_, distWhy_); return SF3D_SOLVER_ERROR; }
+        connected_ = true;
+        return SF3D_OK;
+    }
+    HIP_TRY(hipSetDevice(I.device));
+    DistView& d = I.hostDist;
+    const char* xe = getenv("SF3D_EXCHANGE");
+    bool haveId = false;
+    for (size_t k = 0; k < sizeof(I.rcclId); ++k) if (I.rcclId[k]) haveId = true;
+    if ((xe && std::strcmp(xe, "ipc") == 0) || !I.rcclDistinct || !haveId || !I.load_rccl()) {
+        snprintf(err_, sizeof(err_), "rank %d: the window exchange is not usable (%.120s) and RCCL is not available either (%s)", rank_, distWhy_,
+                 !I.rcclDistinct ? "ranks share a GPU: RCCL needs one GPU per rank" : (!haveId ? "no communicator id in rank 0's blob" : "SF3D_EXCHANGE=ipc / librccl not loadable"));
         return SF3D_SOLVER_ERROR;
     }
-    if (useRccl) {
-        if (I.v.heat.on) { snprintf(err_, sizeof(err_), "the RCCL exchange does not carry the coupled heat step (window exchange only)"); return SF3D_SOLVER_ERROR; }
-        d.rccl = 1; d.mine = I.rcclMine; d.gathered = I.rcclGathered;
-        for (int r = 0; r < world_; ++r) {
-            double *sb = nullptr, *rb = nullptr;
-            HIP_TRY(dev_alloc(I.allocs, sb, (size_t)d.sendCount[r] * 2)); HIP_TRY(dev_alloc(I.allocs, rb, (size_t)d.recvCount[r] * 2));
-            d.sendBuf[r] = sb; d.recvBuf[r] = rb;
-        }
-        I.v.haloDirect = 0;                  /* sweeps read the halo from the arrays the unpack filled, not from a window */
-        I.useFused = 0;                      /* the exchange sits BETWEEN the kernels: separate decision kernels */
-        I.rcclMode = true;
-        if (rank_ == 0) fprintf(stderr, "sf3d: multi-GPU exchange over RCCL (ncclSend/ncclRecv halos + ncclAllGather of the partial sums)%s%s\n", why[0] ? ": " : "", why);
-        HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
+    if (I.v.heat.on) { snprintf(err_, sizeof(err_), "the RCCL exchange does not carry the coupled heat step (window exchange only)"); return SF3D_SOLVER_ERROR; }
+    ncclUniqueId id;
+    std::memcpy(&id, I.rcclId, sizeof(id));
+    if (I.pCommInitRank(&I.comm, world_, id, rank_) != ncclSuccess) { I.comm = nullptr; snprintf(err_, sizeof(err_), "rank %d: ncclCommInitRank failed", rank_); return SF3D_SOLVER_ERROR; }
+    HIP_TRY(dev_alloc(I.allocs, I.rcclMine, 4)); HIP_TRY(dev_alloc(I.allocs, I.rcclGathered, (size_t)3 * world_ + 1));
+    d.rccl = 1; d.mine = I.rcclMine; d.gathered = I.rcclGathered;
+    for (int r = 0; r < world_; ++r) {
+        double *sb = nullptr, *rb = nullptr;
+        HIP_TRY(dev_alloc(I.allocs, sb, (size_t)d.sendCount[r] * 2)); HIP_TRY(dev_alloc(I.allocs, rb, (size_t)d.recvCount[r] * 2));
+        d.sendBuf[r] = sb; d.recvBuf[r] = rb;
     }
+    I.v.haloDirect = 0;                  /* sweeps read the halo from the arrays the unpack filled, not from a window */
+    I.useFused = 0;                      /* the exchange sits BETWEEN the kernels: separate decision kernels */
+    I.rcclMode = true;
+    if (rank_ == 0) fprintf(stderr, "sf3d: multi-GPU exchange over RCCL (ncclSend/ncclRecv halos + ncclAllGather of the partial sums)%s%s\n", distWhy_[0] ? ": " : "", distWhy_);
+    HIP_TRY(hipMemcpy(I.devDist, &d, sizeof(DistView), hipMemcpyHostToDevice));
     connected_ = true;
     return SF3D_OK;
 }
@@ -3137,7 +3143,7 @@ sf3d_error_t DeviceSolver::total_water_content(HostModel& m, const ParamsHost& p
 {
     sf3d_error_t e = sync_to_device(m, p);
     if (e != SF3D_OK) return e;
-    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect"); return SF3D_SOLVER_ERROR; }
+    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect / sf3d_dist_finalize%s%.150s", distWhy_[0] ? ": " : "", distWhy_); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     hipLaunchKernelGGL(k_storage, dim3(I.v.nb), dim3(SF3D_BLOCK), 0, I.stream, I.v);
     if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, dim3(1), dim3(SF3D_BLOCK), 0, I.stream, I.v, 0); I.rccl_gather(I.stream); }
@@ -3244,7 +3250,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
 {
     sf3d_error_t e = sync_to_device(m, p);
     if (e != SF3D_OK) return e;
-    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect"); return SF3D_SOLVER_ERROR; }
+    if (world_ > 1 && !connected_) { snprintf(err_, sizeof(err_), "multi-GPU model used before sf3d_dist_connect / sf3d_dist_finalize%s%.150s", distWhy_[0] ? ": " : "", distWhy_); return SF3D_SOLVER_ERROR; }
     Impl& I = *impl_;
     const DevView& v = I.v;
     const dim3 grid(v.nb), block(SF3D_BLOCK), one(1);

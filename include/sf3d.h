@@ -368,6 +368,13 @@ int          sf3d_dist_blob_bytes(void);
 sf3d_error_t sf3d_dist_prepare(int rank, int world);
 sf3d_error_t sf3d_dist_export(void* blob_out);
 sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
+/* Which exchange: sf3d_dist_connect opens the peers' windows and checks them (one value through every window, both ways, bounded).
+ * sf3d_dist_status() then says what THIS rank found: 0 = its windows work, 1 = they do not (or SF3D_EXCHANGE=rccl asks for RCCL).
+ * The launcher all-gathers that one value and calls sf3d_dist_finalize(any rank said 1) on every rank: 0 keeps the windows, 1 joins
+ * the RCCL communicator whose id rank 0 put into its blob (collective: ncclCommInitRank) and moves halos with ncclSend/ncclRecv and the
+ * partial sums with ncclAllGather.  Launchers that skip the two calls get the windows, or an error at the first step if they failed. */
+int          sf3d_dist_status(void);
+sf3d_error_t sf3d_dist_finalize(int use_rccl);
 /* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
 /* Host logic, no device needed: SF3D_OK and the shape if the staged node graph is a regular NX x NY x NZ grid in layer-major
  * numbering i = (l NY + r) NX + c with the ten-link stencil (slot 0 up, 1 down, laterals to the 8-neighbourhood of the layer;

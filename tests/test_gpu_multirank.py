@@ -104,3 +104,28 @@ def test_sharded_heat_matches_oracle(oracle, tmp_path, world, port):
             np.testing.assert_allclose(res[f"dts_h{h}"], dts, rtol=1e-12)
         assert np.max(np.abs(T[soil] - To[soil]) / To[soil]) < RTOL
         assert np.max(np.abs(H - Ho) / np.maximum(np.abs(Ho), 1e-9)) < RTOL
+
+
+def test_forced_rccl_on_a_shared_gpu_fails_loudly(tmp_path, monkeypatch):
+    """SF3D_EXCHANGE=rccl asks for the ncclSend/ncclRecv exchange; with two ranks on ONE GPU there is no communicator to be had
+    (RCCL refuses two ranks on a device): every rank reports it at connect time - nothing hangs, nothing falls back silently"""
+    monkeypatch.setenv("SF3D_EXCHANGE", "rccl")
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), "2", "29631", "c2f20", str(tmp_path / f"r{r}.npz")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode != 0 for p in procs), logs
+    assert all("RCCL" in o and "one GPU per rank" in o for o in logs), logs
+
+
+def test_connect_without_finalize_keeps_the_windows(tmp_path):
+    """a launcher written for round 1 (export, all-gather, connect - no status / finalize round) still gets the window exchange"""
+    ranks = run_ranks(2, "c2f20_nofinalize", tmp_path, 29632)
+    assert all((res["counters"] == ranks[0]["counters"]).all() for res in ranks) and ranks[0]["counters"][1] == 35
