@@ -1628,6 +1628,10 @@ __device__ __forceinline__ int32_t pair_loff(uint32_t n, int32_t k)
     return n < 9u ? lat : (n == SF3D_PAIR_UP ? up : (n == SF3D_PAIR_DOWN ? down : 0));
 }
 
+#ifndef SF3D_PAIR_PREFETCH
+#define SF3D_PAIR_PREFETCH 0      /* 1: request layer t + 1's coefficient row before the barrier of step t (software pipeline): needs ~100 VGPRs, i.e. 85
+                                 * spilled at the 80 of six waves per SIMD - compiled out (kept for parts with a larger register budget per wave) */
+#endif
 #ifndef SF3D_PAIR_WAVES
 #define SF3D_PAIR_WAVES 6      /* waves per SIMD the register budget is cut for: two blocks of eleven waves per CU at W = 10 */
 #endif
@@ -1675,6 +1679,87 @@ __global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(De
     sf3d_d2* park = &parked[0][(wave >= 1 && wave <= W - 2) ? wave - 1 : 0][lane];
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     constexpr size_t PSTRIDE = (size_t)(W - 2) * 64;
+    const bool active = prow < W && ok;
+#if SF3D_PAIR_PREFETCH
+    /* software pipeline: the coefficient row, b, z and the slot code of layer t + 1 are requested before the barrier of step t and
+     * arrive under stage B of layer t - 1 - the 80 B/node that come from HBM; the gathers of x (L2 / Infinity Cache) stay in stage A */
+    auto fetch_row = [&](int t, double (&a)[SF3D_SLOTS], double& bb, double& zz, uint64_t& code) {
+        const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
+        code = 0;
+        if (rowWave) code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];      /* scalar load */
+        if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
+        #pragma unroll
+        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(A2 + (size_t)p * v.N, i)); a[2 * p] = w.x; a[2 * p + 1] = w.y; }
+        bb = *at32(v.b, i); zz = *at32(v.z, i);
+    };
+    double ac[SF3D_SLOTS], bc = 0., zc = 0.;
+    uint64_t codeC = 0, codeP = 0;
+    #pragma unroll
+    for (int s = 0; s < SF3D_SLOTS; ++s) ac[s] = 0.;
+    if (active && NZ > 0) fetch_row(0, ac, bc, zc, codeC);
+    __syncthreads();
+    for (int t = 0; t <= NZ; ++t) {
+        if (t < NZ && prow < W) {                              /* stage A: x' of layer t */
+            double x1 = 0.;
+            if (ok) {
+                const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
+                double xj[SF3D_SLOTS];
+                const double xi = *at32(xin, i);
+                #pragma unroll
+                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = *at32(xin, (uint32_t)((int32_t)i + tabG[pair_nib(codeC, s)]));
+                x1 = bc;
+                #pragma unroll
+                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ac[s] != 0.) x1 -= ac[s] * xj[s]; }
+                if (t == 0) x1 = dmax(x1, zc);
+                if (owned) {
+                    double d = fabs(x1 - xi);
+                    const double psi = fabs(x1 - zc);
+                    if (psi > 1.) d *= (1. / psi);
+                    n1 += d;
+                    *at32(xo1, i) = x1;
+                }
+            }
+            ring[t & 3][prow][slot] = x1;
+        }
+        /* this layer's row goes to its LDS parking place (thread-private slots: no barrier needed), the previous layer's comes back */
+        double ap[SF3D_SLOTS];
+        sf3d_d2 bz; bz.x = 0.; bz.y = 0.;
+        if (owned) {
+            #pragma unroll
+            for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
+                const sf3d_d2 w = park[(size_t)p * PSTRIDE];
+                sf3d_d2 n; n.x = ac[2 * p]; n.y = ac[2 * p + 1];
+                park[(size_t)p * PSTRIDE] = n;
+                ap[2 * p] = w.x; ap[2 * p + 1] = w.y;
+            }
+            bz = park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE];
+            { sf3d_d2 n; n.x = bc; n.y = zc; park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE] = n; }
+        }
+        const uint64_t codeB = codeP;
+        codeP = codeC;
+        if (active && t + 1 < NZ) fetch_row(t + 1, ac, bc, zc, codeC);          /* in flight across the barrier and stage B */
+        __syncthreads();
+        if (owned && t >= 1) {                                 /* stage B: x'' of layer t - 1 from the ring */
+            const int l = t - 1;
+            const uint32_t i = (uint32_t)l * (uint32_t)layer + i0;
+            const double* own = &ring[l & 3][0][0] + ownPos;
+            double xj[SF3D_SLOTS];
+            const int32_t* tl = tabL[l & 3];
+            #pragma unroll
+            for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = own[tl[pair_nib(codeB, s)]];
+            const double x1 = own[0];
+            double x2 = bz.x;
+            #pragma unroll
+            for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ap[s] != 0.) x2 -= ap[s] * xj[s]; }
+            if (l == 0) x2 = dmax(x2, bz.y);
+            double d = fabs(x2 - x1);
+            const double psi = fabs(x2 - bz.y);
+            if (psi > 1.) d *= (1. / psi);
+            n2 += d;
+            *at32(xo2, i) = x2;
+        }
+    }
+#else
     __syncthreads();
     for (int t = 0; t <= NZ; ++t) {
         double ac[SF3D_SLOTS], bc = 0., zc = 0.;
@@ -1745,6 +1830,7 @@ __global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(De
             }
         }
     }
+#endif
     /* both norms: waves in order inside the block, blocks in index order by the block that arrives last */
     for (int off = 32; off > 0; off >>= 1) { n1 += __shfl_down(n1, off, 64); n2 += __shfl_down(n2, off, 64); }
     if (lane == 0) { sm[0][wave] = n1; sm[1][wave] = n2; }
