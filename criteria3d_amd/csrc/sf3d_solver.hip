@@ -1122,6 +1122,9 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
+#ifndef SF3D_ASM_DIST_FROM_DESC
+#define SF3D_ASM_DIST_FROM_DESC 0   /* 1: chunk-uniform link distances from the descriptor (scalar) instead of the 80 B/node ldist stream */
+#endif
 #ifndef SF3D_ASM_UNIFORM_PATH
 #define SF3D_ASM_UNIFORM_PATH 1   /* scalar-geometry path for chunks whose ChunkDesc::soilUniform is set */
 #endif
@@ -1163,7 +1166,11 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                     if (cd.kind[s] == CK_MIXED) { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
                     else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
                     area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : load_stream<NT>(&v.larea[e]);
+#if SF3D_ASM_DIST_FROM_DESC
+                    dist[t] = ((cd.distUniform >> s) & 1u) ? cd.dist[s] : load_stream<NT>(&v.ldist[e]);
+#else
                     dist[t] = load_stream<NT>(&v.ldist[e]);
+#endif
                 }
             }
             #pragma unroll

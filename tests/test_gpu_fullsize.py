@@ -164,3 +164,30 @@ def test_ravone_dem_coupled_heat_first_step(product, oracle):
     assert np.max(np.abs(gT - oT) / oT) < 1e-6
     assert np.max(np.abs(gH - oH) / np.maximum(np.abs(oH), 1e-9)) < 1e-6
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+@pytest.mark.parametrize("shape,w", [((64, 6, 2), "6"), ((64, 7, 3), "6"), ((128, 9, 2), "6"), ((128, 11, 4), "10"), ((64, 23, 5), "10"), ((192, 14, 3), "14"),
+                                     ((64, 64, 10), "14")])
+def test_paired_sweep_on_awkward_grids(product, shape, w):
+    """k_sweep_pair against k_sweep on grids at the edges of its patch logic: two layers only, fewer rows than two patches, a last
+    patch that is shifted up instead of hanging over the edge, several column patches - same H, Se and accepted steps, bit for bit"""
+    from tests.scenarios import env
+    nx, ny, nz = shape
+    m = cm.catchment_model(nx, ny, nz)
+    res = []
+    for pair in ("0", "1"):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w):
+            product.check(product.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(product, m)
+            product.check(product.lib.sf3d_kernel_timing(1), "timing")       # event statistics tell which sweep kernel ran
+            _, d0 = cm.run_hour(product, m, 30.0)
+            _, d1 = cm.run_hour(product, m, 0.0, max_steps=40)
+            stats = product.kernel_stats()
+            product.lib.sf3d_kernel_timing(0)
+            assert (stats["k_sweep_pair"][0] > 0) == (pair == "1") and (stats["k_sweep"][0] > 0) == (pair == "0"), stats
+            res.append((np.array(d0 + d1), cm.snapshot(product, m), product.counters()))
+        product.lib.sf3d_clean()
+    (da, sa, ca), (db, sb, cb) = res
+    assert np.array_equal(da, db)
+    assert np.array_equal(sa["H"], sb["H"]) and np.array_equal(sa["Se"], sb["Se"])
+    assert ca == cb
