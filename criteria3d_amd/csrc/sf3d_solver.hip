@@ -1148,6 +1148,11 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
+#if SF3D_ASM_DIST_FROM_DESC == 2
+        __shared__ double sdistAll[SF3D_BLOCK / 64][16];
+        double* sdist = sdistAll[threadIdx.x >> 6];
+        if (lane_ < SF3D_SLOTS) sdist[lane_] = v.cdesc[q].dist[lane_];
+#endif
         const double Hoi = Xh[i], Ki = v.K[i];
         const double Ci = v.C[i], flowi = v.flow[i];       /* for the row's diagonal and right-hand side: requested with the first loads, not after the last logarithm */
         double k[SF3D_SLOTS];
@@ -1166,7 +1171,11 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                     if (cd.kind[s] == CK_MIXED) { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
                     else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
                     area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : load_stream<NT>(&v.larea[e]);
-#if SF3D_ASM_DIST_FROM_DESC
+#if SF3D_ASM_DIST_FROM_DESC == 2
+                    /* chunk-uniform distance: the descriptor's ten distances were staged in LDS by the wave (one 80-byte load per chunk);
+                     * every lane reads the same word - a broadcast, a few cycles, no scalar registers */
+                    if (!((cd.distUniform >> s) & 1u)) dist[t] = load_stream<NT>(&v.ldist[e]);      /* else: sdist[s], read where it is used */
+#elif SF3D_ASM_DIST_FROM_DESC
                     dist[t] = ((cd.distUniform >> s) & 1u) ? cd.dist[s] : load_stream<NT>(&v.ldist[e]);
 #else
                     dist[t] = load_stream<NT>(&v.ldist[e]);
@@ -1179,11 +1188,16 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
             for (int t = 0; t < GS; ++t) {
                 const uint32_t s = order[g * GS + t];
                 double ks = 0.;
+#if SF3D_ASM_DIST_FROM_DESC == 2
+                const double dd = ((cd.distUniform >> s) & 1u) ? sdist[s] : dist[t];
+#else
+                const double dd = dist[t];
+#endif
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
-                    ks = (mean_of(ki, kn, meanType) * area[t]) / dist[t];
+                    ks = (mean_of(ki, kn, meanType) * area[t]) / dd;
                 } else if (kd[t] == LK_SOIL_VERT) {
-                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dist[t];
+                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dd;
                 } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
                     ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
                 }                                                            /* a soil row has no runoff link */
