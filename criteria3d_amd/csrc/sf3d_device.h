@@ -142,6 +142,7 @@ struct Ctrl {
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
     uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
+    uint64_t singleLaunches;  /* k_sweep launches that really ran (next to paired sweeps: the odd iteration of an approximation) */
     uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */
     uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
     uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */

@@ -1598,7 +1598,7 @@ __device__ __forceinline__ void body_sweep(const DevView& v)
         if (!dist_allgather(v, v.ctrl, vals, 0)) return;                  /* also the barrier that makes the neighbours' puts visible */
         if (!v.haloDirect) dist_unpack(v, par, DF_X, v.X[nxt]);           /* neighbours' new iterate on my halo */
     }
-    if (threadIdx.x == 0) sweep_decision(v.ctrl, nxt, vals[0] / v.N);
+    if (threadIdx.x == 0) { v.ctrl->singleLaunches++; sweep_decision(v.ctrl, nxt, vals[0] / v.N); }
 }
 template <int MODE, bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
@@ -3465,7 +3465,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     std::memcpy(before, mirror_.counters, sizeof(before));
     std::memcpy(atStart, mirror_.counters, sizeof(atStart));
     int guard = 0;
-    uint64_t pairBefore = mirror_.pairLaunches;
+    uint64_t pairBefore = mirror_.pairLaunches, singleBefore = mirror_.singleLaunches;
 
     const dim3 propsGrid = resident((const void*)k_props<0, false>), propsHeatGrid = resident((const void*)k_props<0, true>);
     const dim3 acceptGrid = v.ntStream ? resident((const void*)k_accept<true>) : resident((const void*)k_accept<false>);
@@ -3515,9 +3515,15 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
             hipLaunchKernelGGL(k_cg_finish, grid, block, 0, st, v);
         } else
-        if (pairOn) {      /* two Jacobi iterations per launch (regular grid, one GPU): ceil(chunk / 2) launches */
+        if (pairOn) {      /* two Jacobi iterations per launch (regular grid, one GPU).  `chunk` = expected iterations + 1: floor(expected / 2)
+                            * pairs, a single sweep when the expectation is odd (122 us instead of a 175 us pair whose second half
+                            * would be thrown away), then one more pair as the margin (a guarded no-op when the expectation holds) */
             const dim3 pgr(I.pairBlocks), pbl((v.pair.W + 1) * 64);
-            for (uint32_t k = 0; k < (chunk + 1) / 2; ++k)
+            const uint32_t expected = chunk > 1 ? chunk - 1 : 1;
+            static const bool oddSingle = !(getenv("SF3D_PAIR_ODD_SINGLE") && getenv("SF3D_PAIR_ODD_SINGLE")[0] == '0');
+            const uint32_t nPairs = oddSingle ? expected / 2 + 1 : (chunk + 1) / 2, singleAfter = (oddSingle && (expected & 1u)) ? expected / 2 : UINT32_MAX;
+            for (uint32_t k = 0; k < nPairs; ++k) {
+                if (k == singleAfter) timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<1, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<1, false>), grid, block, 0, st, v); });
                 timed(KID_SWEEP_PAIR, [&] {
                     switch (v.pair.W * 2 + (v.ntStream ? 1 : 0)) {
                         case 12: hipLaunchKernelGGL((k_sweep_pair<6, false>), pgr, pbl, 0, st, v); break;
@@ -3528,6 +3534,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                         default: hipLaunchKernelGGL((k_sweep_pair<14, true>), pgr, pbl, 0, st, v); break;
                     }
                 });
+            }
         } else
         for (uint32_t k = 0; k < chunk; ++k) {
             if (fused) { timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<1, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<1, false>), grid, block, 0, st, v); }); continue; }
@@ -3608,7 +3615,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
              * comes from the device counters; guarded no-op launches are the shortest of a group */
             uint64_t ran[KID_COUNT];
             ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
-            ran[KID_SWEEP] = pairOn ? 0 : c.counters[3] - before[3];
+            ran[KID_SWEEP] = pairOn ? c.singleLaunches - singleBefore : c.counters[3] - before[3];
             ran[KID_SWEEP_PAIR] = c.pairLaunches - pairBefore;
             if (fuse0) ran[KID_SWEEP] -= (c.counters[2] - before[2]) - (c.counters[4] - before[4]);   /* first iterations: inside k_assemble */
             ran[KID_POST] = c.counters[7] - before[7];
@@ -3627,7 +3634,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             }
         }
         std::memcpy(before, c.counters, sizeof(before));
-        pairBefore = c.pairLaunches;
+        pairBefore = c.pairLaunches; singleBefore = c.singleLaunches;
 
         stage = c.stage;
         if (stage != ST_SWEEP && c.iter > 0) I.lastSweeps = c.iter;

@@ -184,7 +184,8 @@ def test_paired_sweep_on_awkward_grids(product, shape, w):
             _, d1 = cm.run_hour(product, m, 0.0, max_steps=40)
             stats = product.kernel_stats()
             product.lib.sf3d_kernel_timing(0)
-            assert (stats["k_sweep_pair"][0] > 0) == (pair == "1") and (stats["k_sweep"][0] > 0) == (pair == "0"), stats
+            # (with the paired sweep on, an approximation expected to take an odd number of iterations gets one single sweep too)
+            assert (stats["k_sweep_pair"][0] > 0) == (pair == "1") and (pair == "1" or stats["k_sweep"][0] > 0), stats
             res.append((np.array(d0 + d1), cm.snapshot(product, m), product.counters()))
         product.lib.sf3d_clean()
     (da, sa, ca), (db, sb, cb) = res
