@@ -1313,132 +1313,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_
     body_assemble<FUSED, NT, HEAT, SWEEP0, false>(v);
 }
 
-/* ---- Jacobi-preconditioned conjugate gradients: the device's stand-in for the linealia hook (cpusolver.cpp:608-669) ------------
- * The reference hands the row-normalised system A~ x = b~ (A~ = D^-1 S, S symmetric: every conductance is computed from both ends
- * with the same formula) to the third-party library with max_iterations = the Jacobi budget and max_relative_residual_norm =
- * residualTolerance, clamps the surface heads to the ground afterwards and always reports success.  Conjugate gradients on S with
- * the preconditioner D are the same iteration written on the normalised rows: z = r~ (the normalised residual), inner products
- * weighted with the diagonal d that store_row keeps for this purpose.  One iteration = three guarded launches:
- *   k_cg_matvec   q = A~ p, partial sums of p d q          -> last block: alpha
- *   k_cg_update   x += alpha p, r~ -= alpha q, sums of d r~^2 and r~^2 -> last block: beta, stopping test (||r~|| / ||b~|| < tol, budget)
- *   k_cg_dir      p = r~ + beta p
- * k_cg_init computes the first residual into a free head buffer's companion vectors; k_cg_finish clamps and moves on to ST_POST.
- * Single GPU.  The iteration count goes into the sweep counter. */
-template <class F>
-__device__ __forceinline__ double cg_row(const DevView& v, const sf3d_d2* __restrict__ A2, uint32_t q, uint32_t i, const double* __restrict__ vec, F self)
-{
-    double a[SF3D_SLOTS]; uint32_t j[SF3D_SLOTS];
-    #pragma unroll
-    for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 t = A2[(size_t)p * v.N + i]; a[2 * p] = t.x; a[2 * p + 1] = t.y; }
-    const ChunkDesc cd = v.cdesc[q];
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) j[s] = (cd.kind[s] != CK_MIXED) ? i + cd.delta[s] : v.lto[(size_t)s * v.N + i];
-    double acc = self(vec[i]);                           /* diagonal of the normalised row = 1 */
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) if (a[s] != 0.) acc += a[s] * vec[j[s]];
-    return acc;
-}
-__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_init(DevView v)
-{
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 0) return;
-    const int nxt = free_buffer(c);
-    const double* __restrict__ x = v.X[c->cur];
-    double* __restrict__ xn = v.X[nxt];
-    const sf3d_d2* __restrict__ A2 = cur_A2(v);
-    double rho = 0., b2 = 0.;
-    FOR_EACH_CHUNK(v) {
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
-        const double ax = cg_row(v, A2, q, i, x, [](double s) { return s; });
-        const double bi = v.b[i], r = bi - ax, d = v.cgDiag[i];
-        xn[i] = x[i]; v.cgR[i] = r; v.cgP[i] = r;
-        rho += d * r * r; b2 += bi * bi;
-    }
-    const double s0 = block_sum(rho), s1 = block_sum(b2);
-    if (!arrive_last(v, s0, s1, true)) return;
-    const double R = sum_published(v.part0, gridDim.x), B = sum_published(v.part1, gridDim.x);
-    if (threadIdx.x == 0) {
-        c->cgRho = R; c->cgBnorm2 = B; c->cgX = nxt; c->iter = 0;
-        c->cgState = (!(B > 0.) || !(R > 0.)) ? 2u : 1u;      /* b = 0 or an exact start: nothing to iterate */
-    }
-}
-__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_matvec(DevView v)
-{
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
-    const sf3d_d2* __restrict__ A2 = cur_A2(v);
-    double pq = 0.;
-    FOR_EACH_CHUNK(v) {
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
-        const double qi = cg_row(v, A2, q, i, v.cgP, [](double s) { return s; });
-        v.cgQ[i] = qi;
-        pq += v.cgP[i] * v.cgDiag[i] * qi;
-    }
-    const double s0 = block_sum(pq);
-    if (!arrive_last(v, s0, 0., false)) return;
-    const double PQ = sum_published(v.part0, gridDim.x);
-    if (threadIdx.x == 0) {
-        if (PQ > 0.) c->cgAlpha = c->cgRho / PQ;
-        else { c->cgAlpha = 0.; c->cgState = 2; }         /* breakdown (not positive definite, or NaN): stop with what we have */
-    }
-}
-__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_update(DevView v)
-{
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
-    double* __restrict__ x = v.X[c->cgX];
-    const double alpha = c->cgAlpha;
-    double rho = 0., r2 = 0.;
-    FOR_EACH_CHUNK(v) {
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
-        x[i] += alpha * v.cgP[i];
-        const double r = v.cgR[i] - alpha * v.cgQ[i];
-        v.cgR[i] = r;
-        rho += v.cgDiag[i] * r * r; r2 += r * r;
-    }
-    const double s0 = block_sum(rho), s1 = block_sum(r2);
-    if (!arrive_last(v, s0, s1, true)) return;
-    const double R = sum_published(v.part0, gridDim.x), R2 = sum_published(v.part1, gridDim.x);
-    if (threadIdx.x == 0) {
-        c->iter++; c->counters[3]++;
-        c->cgRes2 = R2; c->lastNorm = sqrt(R2 / c->cgBnorm2);
-        c->cgBeta = R / c->cgRho; c->cgRho = R;
-        if (!(R2 > c->residualTolerance * c->residualTolerance * c->cgBnorm2) || c->iter >= c->iterBudget || !(R > 0.)) c->cgState = 2;
-    }
-}
-__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_dir(DevView v)
-{
-    const Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 1) return;
-    const double beta = c->cgBeta;
-    FOR_EACH_CHUNK(v) {
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (i >= v.N) continue;
-        v.cgP[i] = v.cgR[i] + beta * v.cgP[i];
-    }
-}
-/* linealSolver's tail (cpusolver.cpp:657-667): surface heads not below the ground; the solve always counts as valid */
-__global__ void __launch_bounds__(SF3D_BLOCK) k_cg_finish(DevView v)
-{
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP || !c->lineal || c->cgState != 2) return;
-    double* __restrict__ x = v.X[c->cgX];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < v.ns; i += gridDim.x * blockDim.x) {
-        const double zi = v.z[i];
-        if (x[i] - zi < 0.) x[i] = zi;
-    }
-    __syncthreads();
-    if (!arrive_last(v, 0., 0., false)) return;
-    if (threadIdx.x == 0) {
-        c->cur = c->cgX; c->cgState = 0; c->linearValid = 1;
-        if (c->seqCount < 16u) c->seqSweeps[c->seqCount] = c->iter;
-        c->seqCount++;
-        c->stage = ST_POST;
-    }
-}
+#include "sf3d_cg.inc"          /* k_cg_*: preconditioned conjugate gradients standing in for the linealia hook */
 
 /* quirk-1 compat only.  Mirrors the assembly that has just been decided into the emulated row storage of the reference
  * (computeLinearSystemElement cpusolver.cpp:348-389: every existing link writes its conductance at the running column, only a
@@ -1607,275 +1482,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
     body_sweep<MODE, NT>(v);
 }
 
-/* ---- two Jacobi iterations per pass over the coefficient stream (regular grids, one GPU) -------------------------------------
- * JacobiWaterCPU (water.cpp:565-601) twice, driven like two calls of solveLinearSystem's loop body (cpusolver.cpp:672-703).
- * A block owns a patch of W - 2 rows x 64 columns of the horizontal grid and marches down the layers.  Step t:
- *   stage A  every wave computes x' of layer t for its row of the patch - the patch rows plus one halo row above and below
- *            (waves 0 .. W-1) and the two halo columns (wave W, one lane per halo cell) - from the old iterate in HBM, exactly
- *            like k_sweep, and puts it into an LDS ring of four layers; owned cells also store x' and add to the first norm;
- *   stage B  the owned cells compute x'' of layer t - 1 from the ring (layers t - 2, t - 1, t), with the row's coefficients,
- *            right-hand side and z kept in registers from step t - 1, store it and add to the second norm.
- * The 80 B/node of coefficients - 70 % of a sweep's compulsory stream - are read once for two iterations (x 1.25 for the
- * halo rows at W = 10).  x' and x'' are bit-identical to two k_sweep launches: same operands, same order; the norms are
- * the same terms summed over another block layout.  Four ring layers make ONE barrier per layer step sufficient: stage A of
- * step t + 1 writes slot (t + 1) & 3, which no stage B of step t (slots t - 2, t - 1, t) reads.
- * The block that arrives last takes BOTH convergence decisions in order: if the first iteration already ends the loop, H = x'
- * (stored for that purpose) and x'' is ignored - the step count and every later decision are those of single sweeps. */
-/* element idx of a device array with a 32-bit BYTE offset (one VGPR next to a scalar base instead of a 64-bit address pair per access;
- * valid below 2^32 bytes per array - the host enables the paired sweep only for N < 2^28) */
-template <class T> __device__ __forceinline__ const T* at32(const T* base, uint32_t idx)
-{
-    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (idx * (uint32_t)sizeof(T)));
-}
-template <class T> __device__ __forceinline__ T* at32(T* base, uint32_t idx)
-{
-    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (idx * (uint32_t)sizeof(T)));
-}
-__device__ __forceinline__ uint32_t pair_nib(uint64_t code, int s) { return (s < 8 ? (uint32_t)code >> (4 * s) : (uint32_t)(code >> 32) >> (4 * (s - 8))) & 15u; }
-/* index offset of the neighbour a nibble names */
-__device__ __forceinline__ int32_t pair_goff(uint32_t n, int32_t NX, int32_t layer)
-{
-    const int32_t t = (int32_t)((n * 11u) >> 5);                       /* n / 3 for n = 0..8 */
-    const int32_t lat = (t - 1) * NX + ((int32_t)n - 3 * t - 1);
-    return n < 9u ? lat : (n == SF3D_PAIR_UP ? -layer : (n == SF3D_PAIR_DOWN ? layer : 0));
-}
-/* position in the ring relative to the cell's own position in layer l (l & 3 = k), in doubles */
-template <int W>
-__device__ __forceinline__ int32_t pair_loff(uint32_t n, int32_t k)
-{
-    const int32_t t = (int32_t)((n * 11u) >> 5);
-    const int32_t lat = (t - 1) * 66 + ((int32_t)n - 3 * t - 1);
-    const int32_t up = (((k + 3) & 3) - k) * (W * 66), down = (((k + 1) & 3) - k) * (W * 66);
-    return n < 9u ? lat : (n == SF3D_PAIR_UP ? up : (n == SF3D_PAIR_DOWN ? down : 0));
-}
-
-#ifndef SF3D_PAIR_PREFETCH
-#define SF3D_PAIR_PREFETCH 0      /* 1: request layer t + 1's coefficient row before the barrier of step t (software pipeline): needs ~100 VGPRs, i.e. 85
-                                 * spilled at the 80 of six waves per SIMD - compiled out (kept for parts with a larger register budget per wave) */
-#endif
-#ifndef SF3D_PAIR_WAVES
-#define SF3D_PAIR_WAVES 6      /* waves per SIMD the register budget is cut for: two blocks of eleven waves per CU at W = 10 */
-#endif
-/* Registers: the coefficients of layer t - 1 are needed again only after the barrier of step t, by which time the loads of
- * layer t (five 16-byte coefficient loads, b, z, x and ten gathers per lane, all in flight at once) have come and gone: in
- * between they are parked in LDS (thread-private slots, 96 B per owned cell: 49 KB per block at W = 10 next to the 21 KB ring;
- * two blocks per CU use 140 of the 160 KB).  The nibbles of a code are turned into offsets through two small LDS tables
- * (one ds_read per slot instead of a dozen integer instructions per lane). */
-template <int W, bool NT>
-__global__ void __launch_bounds__((W + 1) * 64, SF3D_PAIR_WAVES) k_sweep_pair(DevView v)
-{
-    Ctrl* c = v.ctrl;
-    if (c->stage != ST_SWEEP) return;
-    __shared__ double ring[4][W][66];
-    __shared__ sf3d_d2 parked[SF3D_SLOTS / 2 + 1][W - 2][64];      /* five coefficient pairs + (b, z) */
-    __shared__ int32_t tabG[16], tabL[4][16];
-    __shared__ double sm[2][W + 1];
-    int nxt1, nxt2;
-    free_buffers2(c, nxt1, nxt2);
-    const double* __restrict__ xin = v.X[c->cur];
-    const sf3d_d2* __restrict__ A2 = cur_A2(v);
-    double* __restrict__ xo1 = v.X[nxt1];
-    double* __restrict__ xo2 = v.X[nxt2];
-    const int32_t NX = (int32_t)v.pair.NX, NY = (int32_t)v.pair.NY, NZ = (int32_t)v.pair.NZ;
-    const int32_t layer = NX * NY;
-    if (threadIdx.x < 16) tabG[threadIdx.x] = pair_goff(threadIdx.x, NX, layer);
-    if (threadIdx.x < 64) tabL[threadIdx.x >> 4][threadIdx.x & 15] = pair_loff<W>(threadIdx.x & 15, threadIdx.x >> 4);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pr = blockIdx.x / v.pair.patchCols, pc = blockIdx.x % v.pair.patchCols;
-    int r0 = pr * (W - 2) - 1;
-    if (r0 + W > NY + 1) r0 = NY + 1 - W;          /* the last patch of a column of patches is shifted up instead of hanging over the edge */
-    const int c0 = pc * 64;
-    const bool halo = wave == W;
-    const int prow = halo ? (lane >> 1) : wave;
-    const int r = r0 + prow;
-    const int col = halo ? ((lane & 1) ? c0 + 64 : c0 - 1) : c0 + lane;
-    const int slot = halo ? ((lane & 1) ? 65 : 0) : lane + 1;
-    const bool ok = prow < W && r >= 0 && r < NY && col >= 0 && col < NX;
-    /* every cell is owned by exactly one block; owned rows sit in waves 1 .. W - 2 */
-    const bool owned = !halo && ok && wave >= 1 && wave <= W - 2 && r >= pr * (W - 2) && r < (pr + 1) * (W - 2);
-    const uint32_t i0 = ok ? (uint32_t)(r * NX + col) : 0u;
-    const bool rowWave = !halo && r >= 0 && r < NY;        /* wave-uniform: this wave's 64 cells are chunk (t layer + i0) / 64 */
-    double n1 = 0., n2 = 0.;
-    const int32_t ownPos = (wave < W ? wave : 0) * 66 + lane + 1;      /* own position inside one ring layer (row waves) */
-    sf3d_d2* park = &parked[0][(wave >= 1 && wave <= W - 2) ? wave - 1 : 0][lane];
-    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-    constexpr size_t PSTRIDE = (size_t)(W - 2) * 64;
-    const bool active = prow < W && ok;
-#if SF3D_PAIR_PREFETCH
-    /* software pipeline: the coefficient row, b, z and the slot code of layer t + 1 are requested before the barrier of step t and
-     * arrive under stage B of layer t - 1 - the 80 B/node that come from HBM; the gathers of x (L2 / Infinity Cache) stay in stage A */
-    auto fetch_row = [&](int t, double (&a)[SF3D_SLOTS], double& bb, double& zz, uint64_t& code) {
-        const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
-        code = 0;
-        if (rowWave) code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];      /* scalar load */
-        if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
-        #pragma unroll
-        for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(A2 + (size_t)p * v.N, i)); a[2 * p] = w.x; a[2 * p + 1] = w.y; }
-        bb = *at32(v.b, i); zz = *at32(v.z, i);
-    };
-    double ac[SF3D_SLOTS], bc = 0., zc = 0.;
-    uint64_t codeC = 0, codeP = 0;
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) ac[s] = 0.;
-    if (active && NZ > 0) fetch_row(0, ac, bc, zc, codeC);
-    __syncthreads();
-    for (int t = 0; t <= NZ; ++t) {
-        if (t < NZ && prow < W) {                              /* stage A: x' of layer t */
-            double x1 = 0.;
-            if (ok) {
-                const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
-                double xj[SF3D_SLOTS];
-                const double xi = *at32(xin, i);
-                #pragma unroll
-                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = *at32(xin, (uint32_t)((int32_t)i + tabG[pair_nib(codeC, s)]));
-                x1 = bc;
-                #pragma unroll
-                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ac[s] != 0.) x1 -= ac[s] * xj[s]; }
-                if (t == 0) x1 = dmax(x1, zc);
-                if (owned) {
-                    double d = fabs(x1 - xi);
-                    const double psi = fabs(x1 - zc);
-                    if (psi > 1.) d *= (1. / psi);
-                    n1 += d;
-                    *at32(xo1, i) = x1;
-                }
-            }
-            ring[t & 3][prow][slot] = x1;
-        }
-        /* this layer's row goes to its LDS parking place (thread-private slots: no barrier needed), the previous layer's comes back */
-        double ap[SF3D_SLOTS];
-        sf3d_d2 bz; bz.x = 0.; bz.y = 0.;
-        if (owned) {
-            #pragma unroll
-            for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
-                const sf3d_d2 w = park[(size_t)p * PSTRIDE];
-                sf3d_d2 n; n.x = ac[2 * p]; n.y = ac[2 * p + 1];
-                park[(size_t)p * PSTRIDE] = n;
-                ap[2 * p] = w.x; ap[2 * p + 1] = w.y;
-            }
-            bz = park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE];
-            { sf3d_d2 n; n.x = bc; n.y = zc; park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE] = n; }
-        }
-        const uint64_t codeB = codeP;
-        codeP = codeC;
-        if (active && t + 1 < NZ) fetch_row(t + 1, ac, bc, zc, codeC);          /* in flight across the barrier and stage B */
-        __syncthreads();
-        if (owned && t >= 1) {                                 /* stage B: x'' of layer t - 1 from the ring */
-            const int l = t - 1;
-            const uint32_t i = (uint32_t)l * (uint32_t)layer + i0;
-            const double* own = &ring[l & 3][0][0] + ownPos;
-            double xj[SF3D_SLOTS];
-            const int32_t* tl = tabL[l & 3];
-            #pragma unroll
-            for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = own[tl[pair_nib(codeB, s)]];
-            const double x1 = own[0];
-            double x2 = bz.x;
-            #pragma unroll
-            for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ap[s] != 0.) x2 -= ap[s] * xj[s]; }
-            if (l == 0) x2 = dmax(x2, bz.y);
-            double d = fabs(x2 - x1);
-            const double psi = fabs(x2 - bz.y);
-            if (psi > 1.) d *= (1. / psi);
-            n2 += d;
-            *at32(xo2, i) = x2;
-        }
-    }
-#else
-    __syncthreads();
-    for (int t = 0; t <= NZ; ++t) {
-        double ac[SF3D_SLOTS], bc = 0., zc = 0.;
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) ac[s] = 0.;
-        if (t < NZ && prow < W) {                              /* stage A: x' of layer t */
-            double x1 = 0.;
-            if (ok) {
-                const uint32_t i = (uint32_t)t * (uint32_t)layer + i0;
-                uint64_t code = 0;
-                if (rowWave) code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];      /* scalar load */
-                if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
-                double xj[SF3D_SLOTS];
-                #pragma unroll
-                for (int p = 0; p < SF3D_SLOTS / 2; ++p) { const sf3d_d2 w = load_coeff<NT>(at32(A2 + (size_t)p * v.N, i)); ac[2 * p] = w.x; ac[2 * p + 1] = w.y; }
-                bc = *at32(v.b, i); zc = *at32(v.z, i);
-                const double xi = *at32(xin, i);
-                #pragma unroll
-                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = *at32(xin, (uint32_t)((int32_t)i + tabG[pair_nib(code, s)]));
-                x1 = bc;
-                #pragma unroll
-                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ac[s] != 0.) x1 -= ac[s] * xj[s]; }
-                if (t == 0) x1 = dmax(x1, zc);
-                if (owned) {
-                    double d = fabs(x1 - xi);
-                    const double psi = fabs(x1 - zc);
-                    if (psi > 1.) d *= (1. / psi);
-                    n1 += d;
-                    *at32(xo1, i) = x1;
-                }
-            }
-            ring[t & 3][prow][slot] = x1;
-        }
-        __syncthreads();
-        if (owned) {
-            /* this layer's row goes to its LDS parking place (thread-private slots: no barrier needed) and the previous layer's
-             * comes back from it, pair by pair, so that the two rows are never in registers at the same time */
-            double ap[SF3D_SLOTS];
-            #pragma unroll
-            for (int p = 0; p < SF3D_SLOTS / 2; ++p) {
-                const sf3d_d2 w = park[(size_t)p * PSTRIDE];
-                sf3d_d2 n; n.x = ac[2 * p]; n.y = ac[2 * p + 1];
-                park[(size_t)p * PSTRIDE] = n;
-                ap[2 * p] = w.x; ap[2 * p + 1] = w.y;
-            }
-            const sf3d_d2 bz = park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE];
-            { sf3d_d2 n; n.x = bc; n.y = zc; park[(size_t)(SF3D_SLOTS / 2) * PSTRIDE] = n; }
-            if (t >= 1) {                                      /* stage B: x'' of layer t - 1 from the ring */
-                const int l = t - 1;
-                const uint32_t i = (uint32_t)l * (uint32_t)layer + i0;
-                const double* own = &ring[l & 3][0][0] + ownPos;
-                uint64_t code = v.pair.chunkCode[__builtin_amdgcn_readfirstlane(i >> 6)];          /* owned cells sit in row waves */
-                if (!(code >> 63)) code = *at32(v.pair.nodeCode, i);
-                double xj[SF3D_SLOTS];
-                const int32_t* tl = tabL[l & 3];
-                #pragma unroll
-                for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = own[tl[pair_nib(code, s)]];
-                const double x1 = own[0];
-                double x2 = bz.x;
-                #pragma unroll
-                for (int o = 0; o < SF3D_SLOTS; ++o) { const uint32_t s = order[o]; if (ap[s] != 0.) x2 -= ap[s] * xj[s]; }
-                if (l == 0) x2 = dmax(x2, bz.y);
-                double d = fabs(x2 - x1);
-                const double psi = fabs(x2 - bz.y);
-                if (psi > 1.) d *= (1. / psi);
-                n2 += d;
-                *at32(xo2, i) = x2;
-            }
-        }
-    }
-#endif
-    /* both norms: waves in order inside the block, blocks in index order by the block that arrives last */
-    for (int off = 32; off > 0; off >>= 1) { n1 += __shfl_down(n1, off, 64); n2 += __shfl_down(n2, off, 64); }
-    if (lane == 0) { sm[0][wave] = n1; sm[1][wave] = n2; }
-    __syncthreads();
-    double s1 = 0., s2 = 0.;
-    if (threadIdx.x == 0) for (int w = 0; w <= W; ++w) { s1 += sm[0][w]; s2 += sm[1][w]; }
-    if (!arrive_last(v, s1, s2, true)) return;
-    double t1 = 0., t2 = 0.;
-    if (threadIdx.x < SF3D_BLOCK)
-        for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK) {
-            t1 += __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t2 += __hip_atomic_load(&v.part1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64); }
-    __syncthreads();
-    if (lane == 0) { sm[0][wave] = t1; sm[1][wave] = t2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double a = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), b = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-        c->pairLaunches++;
-        sweep_decision(c, nxt1, a / v.N);                               /* first iteration: H candidate = x' */
-        if (c->stage == ST_SWEEP) sweep_decision(c, nxt2, b / v.N);     /* the loop goes on: second iteration, x'' */
-    }
-}
+#include "sf3d_pair.inc"        /* k_sweep_pair: two Jacobi iterations per pass through an LDS ring */
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
                                               double Se, double& st, double& sk)
@@ -2028,89 +1635,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     body_accept<NT>(v);
 }
 
-/* ---- one computeStep in ONE launch: small grids in the runoff regime ------------------------------------------------------
- * A step there is ~25 launches of a few microseconds of work each (C2 F60: 2.6 approximations and 12 sweeps per step, dt
- * pinned at dtmin, 5 500 steps per simulated hour): kernel boundaries cost more than the kernels.  This kernel walks the same
- * stage machine with the same phase bodies - body_props / body_assemble / body_sweep / body_post / body_restore / body_accept,
- * decisions in the block that arrives last - and puts a grid barrier where the kernel boundaries were.  All blocks are resident
- * at once (the host sizes the grid from the occupancy query), every block takes the same branch because the stage only changes
- * inside a phase, before the barrier that ends it.  Between phases: agent-scope release before the arrival (this XCD's L2 is
- * written back: the next phase reads across XCDs), acquire + scalar-cache invalidate after it (the control block is read
- * through the scalar path and changes from phase to phase).  A bounded wait turns blocks that are not co-resident into a failed
- * step instead of a hung GPU. */
-__device__ __forceinline__ bool grid_barrier(const DevView& v, unsigned int& gen)
-{
-    __shared__ int sOk;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        gen += gridDim.x;
-        __hip_atomic_fetch_add(v.gridBar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        const long long t0 = wall_clock64();
-        while ((int)(__hip_atomic_load(v.gridBar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 300000000LL) { ok = 0; break; }      /* 3 s at 100 MHz */
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        sOk = ok;
-    }
-    __syncthreads();
-    __builtin_amdgcn_s_dcache_inv();       /* (the vector L1 of this CU was invalidated by thread 0's acquire) */
-    return sOk != 0;
-}
-
-#ifndef SF3D_PERSIST_WAVES
-#define SF3D_PERSIST_WAVES 2      /* all six phases in one body need ~230 VGPRs; the grids this kernel serves fill the GPU with two waves per SIMD or fewer */
-#endif
-/* the phases, inlined: the view stays a kernel argument (scalar registers, global address space).  SF3D_PHASE_NOINLINE=1 compiles
- * them as real functions instead (own register allocation each, but the view then travels through memory and its pointers
- * become generic: measured slower) */
-#ifndef SF3D_PHASE_NOINLINE
-#define SF3D_PHASE_NOINLINE 0
-#endif
-#if SF3D_PHASE_NOINLINE
-#define SF3D_PHASE __device__ __attribute__((noinline)) void
-#define SF3D_PHASE_B __device__ __attribute__((noinline)) bool
-#else
-#define SF3D_PHASE __device__ __forceinline__ void
-#define SF3D_PHASE_B __device__ __forceinline__ bool
-#endif
-SF3D_PHASE phase_props(const DevView& v) { body_props<0, false>(v); }
-template <bool NT> SF3D_PHASE phase_assemble(const DevView& v) { body_assemble<true, NT, false, false, true>(v); }
-template <bool NT> SF3D_PHASE phase_sweep(const DevView& v) { body_sweep<1, NT>(v); }
-SF3D_PHASE phase_post(const DevView& v) { body_post<true>(v); }
-SF3D_PHASE phase_restore(const DevView& v) { body_restore<true, false>(v); }
-template <bool NT> SF3D_PHASE phase_accept(const DevView& v) { body_accept<NT>(v); }
-SF3D_PHASE_B phase_barrier(const DevView& v, unsigned int& gen) { return grid_barrier(v, gen); }
-
-template <bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_PERSIST_WAVES) k_step_persistent(DevView v, double maxTimeStep)
-{
-    Ctrl* c = v.ctrl;
-    unsigned int gen = __hip_atomic_load(&c->barGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c->maxTimeStep = maxTimeStep; c->seqCount = 0; c->aBuf ^= 1u; begin_attempt(c); }
-    bool ok = phase_barrier(v, gen);
-    for (uint32_t guard = 0; ok && guard < 100000u; ++guard) {
-        const uint32_t stage = __hip_atomic_load(&c->stage, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (stage == ST_APPROX) {
-            phase_props(v);
-            ok = phase_barrier(v, gen);
-            if (!ok) break;
-            phase_assemble<NT>(v);
-        }
-        else if (stage == ST_SWEEP) phase_sweep<NT>(v);
-        else if (stage == ST_POST) phase_post(v);
-        else if (stage == ST_RESTORE) phase_restore(v);
-        else if (stage == ST_ACCEPT) { phase_accept<NT>(v); break; }
-        else break;                                            /* ST_FAIL */
-        ok = phase_barrier(v, gen);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (!ok) { c->barTimeout = 1; c->stage = ST_FAIL; }
-        c->barGen = gen;          /* every block made the same number of barriers: the next launch starts from here */
-    }
-}
+#include "sf3d_persistent.inc"  /* k_step_persistent: one launch per computeStep (measured alternative) */
 
 /* The two halves of k_accept for the overlapped mode: the boundary sums stay in the step (the next step's k_props
  * overwrites bflowRate); the link sums - 1.5 GB of traffic at C4, 6 % VALU - run on a second stream next to the next
