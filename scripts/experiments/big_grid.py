@@ -1,6 +1,6 @@
 """One-off: 1024 x 1024 x 20 (21 M nodes, 4 x the headline grid) - index arithmetic beyond 2^31 bytes per array, timing."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from criteria3d_amd import capi, catchment as cm
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
