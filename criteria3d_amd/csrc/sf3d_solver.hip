@@ -1770,6 +1770,7 @@ __global__ void k_dist_ping(DistView d, unsigned long long token, long long time
 struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream3 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;   /* SF3D_ASM_UNIFORM=2: chunk-uniform soil rows next to the general ones */
     hipStream_t stream2 = nullptr;         /* link flow sums of the accepted step, next to the next step's k_props */
     hipEvent_t evLinks[2] = {nullptr, nullptr};   /* one per copy of the matrix: recorded after the link sums that read it */
     bool linksPending[2] = {false, false};
@@ -2198,7 +2199,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             /* OFF by default (SF3D_ASM_UNIFORM=1 turns it on): measured at C4, 166 us for the 71 % uniform chunks + 233 us for the rest, one
              * after the other, against 300 us for everything in one launch - alone, the general rows (row ends, layer 1, surface) are
              * latency-bound at 4 waves/SIMD; inside the single kernel their waiting is hidden by the other rows' arithmetic */
-            const bool want = !m.heat && (ue && ue[0] == '1') && !(fe && fe[0] == '1');
+            const bool want = !m.heat && (ue && (ue[0] == '1' || ue[0] == '2')) && !(fe && fe[0] == '1');
             auto soilBegin = asmOrder.begin() + v.nListSurf;
             auto mid = asmOrder.end();
             if (want) mid = std::stable_partition(soilBegin, asmOrder.end(), [&](uint32_t q) { return cdesc[q].soilUniform == 0; });
@@ -3013,6 +3014,13 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     /* the soil rows with chunk-uniform link geometry: their own low-register kernel, queued before k_assemble (which decides) */
     const dim3 asmUGrid = [&] { const dim3 r = v.ntStream ? resident((const void*)k_assemble_uniform<true>) : resident((const void*)k_assemble_uniform<false>);
                                 return dim3(v.nbAsmU < r.x ? (v.nbAsmU ? v.nbAsmU : 1u) : r.x); }();
+    /* SF3D_ASM_UNIFORM=2: the two assembly kernels side by side on two streams instead of one after the other */
+    static const bool wantConcurrent = getenv("SF3D_ASM_UNIFORM") && getenv("SF3D_ASM_UNIFORM")[0] == '2';
+    const bool concurrentRows = wantConcurrent && v.nAsmGen < v.nList && !multi && !heatOn && I.useFused && !fuse0;
+    if (concurrentRows && !I.stream3) {
+        HIP_TRY(hipStreamCreateWithFlags(&I.stream3, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&I.evFork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&I.evJoin, hipEventDisableTiming));
+    }
     auto launch_uniform_rows = [&] {
         if (v.nAsmGen >= v.nList) return;
         if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
@@ -3024,6 +3032,19 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
             else if (fuse0) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (concurrentRows) timed(KID_ASSEMBLE, [&] {
+                /* the chunk-uniform soil rows on a stream of their own NEXT TO the general rows (fork after k_props, join before the Courant
+                 * decision, which therefore is a kernel of its own here: the stage must not move while either kernel is running) */
+                hipEventRecord(I.evFork, st);
+                hipStreamWaitEvent(I.stream3, I.evFork, 0);
+                if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, I.stream3, v);
+                else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, I.stream3, v);
+                hipEventRecord(I.evJoin, I.stream3);
+                if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
+                else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
+                hipStreamWaitEvent(st, I.evJoin, 0);
+                hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
+            });
             else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
                 timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
@@ -3106,7 +3127,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     };
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
         if (!I.useGraphs || timedStep || I.rcclMode) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }   /* (RCCL calls are queued eagerly) */
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u) | (concurrentRows ? 1u << 24 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);

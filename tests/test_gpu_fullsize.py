@@ -98,6 +98,7 @@ def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
     modes.append(dict(fast, SF3D_PERSISTENT="1"))      # the whole computeStep in one launch (k_step_persistent: grid barriers instead of kernel boundaries)
     auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_PERSISTENT")}   # what a user gets: the library picks sweep and launch form itself
     modes.append(auto)
+    modes.append(dict(fast, SF3D_ASM_UNIFORM="2"))      # the same two assembly kernels side by side on two streams, Courant decision after the join
     modes.append(dict(fast, SF3D_ASM_UNIFORM="1"))      # soil rows with chunk-uniform geometry through k_assemble_uniform (kept as a measured alternative)
     for k, mode in enumerate(modes):
         out = tmp_path / f"{case}_{k}.npz"
