@@ -110,19 +110,29 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=600)
-        except subprocess.TimeoutExpired:
-            p.kill(); p.wait()
+    # rank 0's stdout is drained by a thread; the parent watches every child: one that dies takes the others with it (a rank
+    # waiting in a collective for a dead peer would otherwise hang the run)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst, deadline = 0, time.time() + float(os.environ.get("SF3D_BENCH_TIMEOUT_S", "3000"))
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad or time.time() > deadline:
+            worst = bad[0] if bad else 124
+            log(f"[bench] a rank {'failed' if bad else 'timed out'} (rc {worst}): stopping the others")
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
         if p.returncode != 0 and worst == 0:
             worst = p.returncode
-    if worst != 0:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    reader.join(timeout=5)
+    out0 = "".join(c for c in chunks if c)
     sys.stdout.write(out0 or "")
     sys.stdout.flush()
     sys.exit(worst)

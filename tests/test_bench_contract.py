@@ -92,6 +92,23 @@ def test_bench_spawns_its_own_ranks():
     assert "traffic_source" in line["roofline"]
 
 
+@pytest.mark.gpu
+def test_bench_rank_without_a_gpu_stops_the_run():
+    """two ranks asked for on a box with one GPU (and no SF3D_BENCH_SHARE_GPU): rank 1 has no device of its own and says so; the
+    parent stops rank 0 instead of leaving it waiting in a collective, and returns the failing rank's code"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with ONE GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SF3D_BENCH_SHARE_GPU")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1500:])
+    assert "no GPU of its own" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """--gpus must equal the launcher's WORLD_SIZE; the message says what to do (runs without a GPU: the check comes first)"""
     import os

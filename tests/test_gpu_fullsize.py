@@ -193,3 +193,31 @@ def test_paired_sweep_on_awkward_grids(product, shape, w):
     assert np.array_equal(da, db)
     assert np.array_equal(sa["H"], sb["H"]) and np.array_equal(sa["Se"], sb["Se"])
     assert ca == cb
+
+
+def test_paired_sweep_with_heat_and_with_the_compat_rows(product):
+    """the paired sweep next to the other users of the water system: the coupled heat step (thermal fluxes in the water rows, saved
+    water fluxes read from the matrix) and the quirk-1 emulation (rows stored raw, normalised by k_compat_rows) - bitwise against
+    single sweeps"""
+    from tests.scenarios import env, run_scenario
+    m = cm.with_heat_surface(cm.catchment_model(64, 40, 6, heterogeneous=True))
+    heat = cm.Heat(water=True, latent=True, save_mode=1)
+    res = []
+    for pair in ("0", "1"):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W="10"):
+            product.check(product.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(product, m, heat=heat)
+            dts = []
+            for h, mm in enumerate((4.0, 0.0)):
+                cm.apply_heat_forcing(product, m, h)
+                dts += cm.run_hour(product, m, mm)[1]
+            res.append((np.array(dts), product.total_potential(0, m.n), product.temperature(0, m.n)))
+        product.lib.sf3d_clean()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2][m.ns:], res[1][2][m.ns:])
+    out = []
+    for pair in ("0", "1"):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W="10", SF3D_COMPAT_STALE_LINK_FLOW="1"):
+            out.append(run_scenario(product, "flows_c2_f60"))
+        product.lib.sf3d_clean()
+    for k in out[0]:
+        assert np.array_equal(out[0][k], out[1][k]), k
