@@ -13,7 +13,8 @@ are timed, with the hour's sinks already resident in HBM (sf3d_synchronize() upl
 before the clock starts); a barrier + device synchronize brackets the timed region and the MAX
 over ranks is reported.  `value` = K simulated hours / that time.
 
-The timed region is repeated REPS times (default 3), each from a freshly rebuilt initial state, and the MEDIAN elapsed time
+The timed region is repeated (default: at least 3 times and until 1.5 s have been timed, at most 15; --reps fixes the count), each time from
+the initial state - rewound through the API, not rebuilt, so that the repetitions keep the GPU busy back to back - and the MEDIAN elapsed time
 is reported (`value`, `ms_per_step`; all repetitions in `repeats_s`).  `headline_6h` is the same measurement restricted to the
 timed hours 0-5 - the 6-hour figure SURVEY.md 8d quotes - whenever K >= 6, so that it is driver-timed whatever K is.
 `inclusive_value` puts the hourly sink/source upload (host -> HBM) inside the clock; it is never `value`.
@@ -197,7 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
-    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed region, each from a fresh initial state; the median is reported")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions of the timed region, each from the initial state (rewound, not rebuilt); the median is reported; 0 = at least 3 and as many as it takes to time 1.5 s (at most 15)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (best measured: 16-32)")
     args = ap.parse_args()
@@ -274,6 +275,28 @@ def main():
             sf.lib.sf3d_set_use_lineal(1)
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
 
+    def rewind():
+        """back to the initial state WITHOUT rebuilding the graph (tens of milliseconds instead of seconds, so that the repetitions
+        of the timed region keep the GPU busy back to back): the adaptive time step as a fresh model has it (600 s, SURVEY 8a
+        quirk 4), the initial potentials (and temperatures), balances and flow sums through initializeBalance.  Every repetition must
+        then do exactly the work of the first one - checked below."""
+        sf.check(sf.lib.sf3d_set_time_step(600.0), "set_time_step")
+        if heat is not None and heat.t0_surface is not None:
+            up = model.link_dir == capi.LINK_UP
+            parent = np.arange(model.n); parent[model.link_node[up]] = model.link_to[up]
+            root = parent.copy()
+            for _ in range(64):
+                nxt = parent[root]
+                if np.array_equal(nxt, root):
+                    break
+                root = nxt
+            sf.set_temperature_bulk(0, heat.t0_surface + heat.t0_gradient * (model.z[root] - model.z))
+        psi = np.full(model.n, model.psi0_soil); psi[:model.ns] = model.psi0_surface
+        sf.set_matric_potential_bulk(0, psi)
+        sf.set_sink_source_bulk(0, np.zeros(model.n))
+        sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
+        sf.check(sf.lib.sf3d_synchronize(), "synchronize")
+
     t0 = time.perf_counter()
     fresh()
     log(f"[bench] rank {rank}: graph build + upload in {time.perf_counter() - t0:.1f}s")
@@ -284,24 +307,28 @@ def main():
     # HIP events around the dominant kernel only, on every 8th computeStep (mode 2); --time-all-kernels
     # instruments every node kernel of every step (eager launches, ~6 % slower)
     sf.check(sf.lib.sf3d_kernel_timing(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2)), "kernel_timing")
-    reps = max(1, args.reps)
+    reps = max(1, args.reps) if args.reps > 0 else 3          # --reps 0: at least 3, and as many as it takes to time >= 1.5 s (<= 15)
     rep_elapsed, rep_hours, rep_incl = [], [], []
-    per_step, hour_starts, c0 = [], [], None
-    for rep in range(reps):
+    per_step, hour_starts, c0, work0 = [], [], None, None
+    rep = 0
+    while rep < reps:
         if rep > 0:
             sf.check(sf.lib.sf3d_kernel_timing(0), "kernel_timing")      # event statistics come from the first repetition only
-            fresh()
+            rewind()
         ps, hs_, ph, incl = [], [], [], [0.0]
         barrier()
         torch.cuda.synchronize()
-        if rep == 0:
-            c0 = sf.counters()
+        cb = sf.counters()
         el = run_hours(sf, cm, model, args.forcing, args.steps, per_step=ps, hour_starts=hs_, heat=heat, per_hour=ph, inclusive=incl)
         torch.cuda.synchronize()
+        ca = sf.counters()
+        did = {k: ca[k] - cb[k] for k in ca}
         if rep == 0:
-            c1 = sf.counters()
+            c0, c1, work0 = cb, ca, did
             stats = sf.kernel_stats()
             per_step, hour_starts = ps, hs_
+        elif did != work0:
+            raise RuntimeError(f"rank {rank}: repetition {rep} did other work than the first one ({did} vs {work0}): the rewind is not a fresh start")
         vals = [el, incl[0], sum(ph[:6])] + ph
         if world > 1:
             dist.barrier()
@@ -309,6 +336,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             vals = [float(x) for x in t.tolist()]
         rep_elapsed.append(vals[0]); rep_incl.append(vals[1]); rep_hours.append(vals[2])
+        if rep == 0 and args.reps <= 0 and vals[0] > 0:          # (the maximum over the ranks: the same decision on every rank)
+            reps = int(min(15, max(3, np.ceil(1.5 / vals[0]))))
+        rep += 1
     order = sorted(range(reps), key=lambda k: rep_elapsed[k])
     med = order[reps // 2]
     elapsed, elapsed_incl, elapsed_6h = rep_elapsed[med], rep_incl[med], sorted(rep_hours)[reps // 2]

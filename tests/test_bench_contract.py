@@ -85,7 +85,7 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
-    assert len(line["repeats_s"]) == 2 and min(line["repeats_s"]) > 0
+    assert len(line["repeats_s"]) == 2 and min(line["repeats_s"]) > 0          # --reps 2: rewound, not rebuilt, and checked to do the same work
     assert line["headline_6h"]["value"] > 0 and abs(line["headline_6h"]["value"] - line["value"]) < 0.35 * line["value"]
     assert 0 < line["inclusive_value"] <= line["value"] * 1.02
     assert line["config"]["work"]["accepted"] == 50          # C2 F20: 22 + 13 + 6 + 3 + 3 + 3
