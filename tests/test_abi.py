@@ -256,3 +256,15 @@ def test_vectorised_dem_builder_equals_the_readable_one():
               "link_area", "soil_index"):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
     assert len(cm.dem_layer_thicknesses(0.95)) == 14            # 14 layers for 0.95 m
+
+
+def test_exchange_round_on_one_rank_and_lineal_gate(product):
+    """host logic of the two API additions of round 2 (no device needed): a single-rank model reports healthy windows and accepts either
+    finalize; setUseLineal(true) is inert unless SF3D_LINEAL_DEVICE_CG=1 was set when the model was initialised"""
+    fresh(product)
+    assert product.lib.sf3d_dist_status() == 0
+    assert product.lib.sf3d_dist_finalize(0) == capi.OK and product.lib.sf3d_dist_finalize(1) == capi.OK      # world of one: nothing to join
+    product.lib.sf3d_set_use_lineal(1); product.lib.sf3d_set_lineal_method(1)
+    assert product.lib.sf3d_set_time_step(120.0) == capi.OK and product.lib.sf3d_get_time_step() == 120.0
+    product.lib.sf3d_set_use_lineal(0)
+    product.lib.sf3d_clean()
