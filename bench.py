@@ -134,7 +134,8 @@ def spawn_ranks(n, argv):
             worst = p.returncode
     reader.join(timeout=5)
     out0 = "".join(c for c in chunks if c)
-    sys.stdout.write(out0 or "")
+    for ln in out0.splitlines():           # the JSON line to stdout, anything else a library printed there (gloo's connection notice) to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     sys.exit(worst)
 
