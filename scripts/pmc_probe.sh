@@ -17,7 +17,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in csv.DictReader(open(f[0])):
     k = re.split(r"[<(]", row["Kernel_Name"].replace("void ", ""))[0]
     agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k in ("k_sweep", "k_assemble", "k_props", "k_post", "k_accept"):
+for k in ("k_sweep_pair", "k_sweep", "k_assemble", "k_props", "k_post", "k_accept"):
     for c, v in agg.get(k, {}).items():
         big = [x for x in v if x > 0.25 * max(v)] if max(v) > 0 else v
         print(f"{k:12s} {c:28s} mean_active={sum(big)/max(len(big),1):14.4g}  max={max(v):14.4g} n={len(v)}")
