@@ -187,13 +187,39 @@ __device__ __forceinline__ double reduce_partials_max(const double* p, uint32_t 
     return block_max(s);
 }
 
+/* a / b for the link arithmetic (conductivities, distances, logarithms of conductivity ratios: finite operands of ordinary
+ * magnitude).  The compiler's IEEE sequence is 17 instructions - operand scaling, reciprocal seed, two Newton steps, quotient,
+ * residual, re-scaling, special-case fix-up - and there are thirty divisions per soil row; this one keeps the seed, the Newton
+ * steps and the residual correction (8 instructions, the same <= 1 ulp) and hands everything whose result is not a finite number
+ * (b = 0, denormal or infinite operands, nan) to the full sequence, so that the special cases keep the reference's answers - the
+ * logarithmic mean of two conductivities one ulp apart really divides by log(1) = 0.
+ * OFF by default (-DSF3D_FAST_DIV=1 turns it on): measured at C4, k_assemble 303-305 us with it against 300 us without - the kernel's
+ * time is not in its VALU instruction count, so the exactly rounded quotients stay. */
+#ifndef SF3D_FAST_DIV
+#define SF3D_FAST_DIV 0
+#endif
+__device__ __forceinline__ double qdiv(double a, double b)
+{
+#if SF3D_FAST_DIV
+    double r = __builtin_amdgcn_rcp(b);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+    double q = a * r;
+    q = __builtin_fma(__builtin_fma(-b, q, a), r, q);
+    if (__builtin_expect(!(fabs(q) < __builtin_inf()), 0)) q = a / b;
+    return q;
+#else
+    return a / b;
+#endif
+}
+
 /* ---- Math::computeMean (otherFunctions.cpp:7-36) ---- */
 /* the logarithm is the table-driven one: every kernel that evaluates a mean has called fm_init() */
 __device__ __forceinline__ double mean_of(double v1, double v2, uint32_t type)
 {
     if (type == SF3D_MEAN_ARITHMETIC) return (v1 + v2) * 0.5;
     if (type == SF3D_MEAN_GEOMETRIC) { const int sign = (v1 > 0) - (v1 < 0); return sign * sqrt(v1 * v2); }
-    return (v1 == v2) ? v1 : (v1 - v2) / flog(v1 / v2);
+    return (v1 == v2) ? v1 : qdiv(v1 - v2, flog(qdiv(v1, v2)));
 }
 
 /* ---- Soil:: (soilPhysics.cpp) ---- */
@@ -968,7 +994,7 @@ __device__ __forceinline__ double link_conductance(const DevView& v, const Ctrl*
     if (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT) {
         double ki = v.K[i], kj = v.K[j];
         if (kind == LK_SOIL_LAT) { ki *= c->lvRatio; kj *= c->lvRatio; }
-        return (mean_of(ki, kj, c->meanType) * area) / dist;
+        return qdiv(mean_of(ki, kj, c->meanType) * area, dist);
     }
     if (kind == LK_RUNOFF) {
         double Ha = 0.5 * (Hi + Hoi);
@@ -1195,9 +1221,9 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
 #endif
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
-                    ks = (mean_of(ki, kn, meanType) * area[t]) / dd;
+                    ks = qdiv(mean_of(ki, kn, meanType) * area[t], dd);
                 } else if (kd[t] == LK_SOIL_VERT) {
-                    ks = (mean_of(Ki, kj[t], meanType) * area[t]) / dd;
+                    ks = qdiv(mean_of(Ki, kj[t], meanType) * area[t], dd);
                 } else if (kd[t] == LK_INFILTRATION) {                       /* the surface node above (layer 1) */
                     ks = infiltration_conductance(v, c, i, j[t], (size_t)s * v.N + i, Xc, Xh, Xc[i], Hoi, v.z[i]);
                 }                                                            /* a soil row has no runoff link */
@@ -1256,9 +1282,9 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASMU_WAVES) k_assemble_unifor
             double ks = 0.;
             if (cd.kind[s] == LK_SOIL_LAT) {                             /* redistribution, water.cpp:542-562 */
                 const double ki = Ki * lvRatio, kn = kj[s] * lvRatio;
-                ks = (mean_of(ki, kn, meanType) * cd.area[s]) / cd.dist[s];
+                ks = qdiv(mean_of(ki, kn, meanType) * cd.area[s], cd.dist[s]);
             } else if (cd.kind[s] == LK_SOIL_VERT)
-                ks = (mean_of(Ki, kj[s], meanType) * cd.area[s]) / cd.dist[s];
+                ks = qdiv(mean_of(Ki, kj[s], meanType) * cd.area[s], cd.dist[s]);
             k[s] = ks;
             sum += ks;
             __builtin_amdgcn_sched_barrier(0);
