@@ -66,7 +66,8 @@ struct ChunkDesc {
     uint8_t pad0;                       /* multi GPU: 1 = some node of the chunk has a neighbour owned by another rank */
     uint16_t areaUniform;               /* bit s: every link of slot s in the chunk has interface area area[s] */
     uint16_t sweepUniform;              /* bit s: kind[s] is CK_MIXED only because some nodes lack the link - every existing one has
-                                         * j = i + delta[s] (row ends of a regular grid): the sweep needs no lto there */
+                                         * j = i + delta[s] (row ends of a regular grid, whose laterals the upload aligns with their chunk's
+                                         * slots): neither the sweep nor the assembly reads lto there */
     uint16_t distUniform;               /* bit s: every link of slot s in the chunk has the link distance dist[s] */
     uint8_t soilUniform;                /* 1: a soil-only chunk whose slots are all either empty or one uniform soil-soil link kind with uniform offset,
                                          * area and distance (interior of a regular grid below layer 1): k_assemble's scalar-geometry path */

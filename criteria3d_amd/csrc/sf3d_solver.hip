@@ -1123,6 +1123,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
                 const size_t e = (size_t)s * v.N + i;
                 uint8_t kind; uint32_t j;
                 if (cd.kind[s] != CK_MIXED) { kind = cd.kind[s]; j = i + cd.delta[s]; }
+                else if ((cd.sweepUniform >> s) & 1u) { kind = v.lkind[e]; const uint32_t jj = i + (uint32_t)cd.delta[s]; j = jj < v.N ? jj : i; }
                 else { kind = v.lkind[e]; j = v.lto[e]; }
                 if (kind != LK_NONE) ks = link_conductance(v, c, i, j, e, kind, Xc, Xh, Hi, Hoi, zi, courant);
                 if (HEAT && (kind == LK_SOIL_VERT || kind == LK_SOIL_LAT)) add_thermal_fluxes(v.heat, i, j, v.larea[e], v.heat.hdist[e], invFlux);
@@ -1194,8 +1195,12 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                 kd[t] = LK_NONE; j[t] = i; area[t] = 0.; dist[t] = 1.;
                 if (cd.kind[s] != CK_NONE) {
                     const size_t e = (size_t)s * v.N + i;
-                    if (cd.kind[s] == CK_MIXED) { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
-                    else { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
+                    if (cd.kind[s] != CK_MIXED) { kd[t] = cd.kind[s]; j[t] = i + cd.delta[s]; }
+                    else if ((cd.sweepUniform >> s) & 1u) {     /* row end: one offset for the nodes that have the link - the gather does not wait for an index */
+                        kd[t] = load_stream<NT>(&v.lkind[e]);
+                        const uint32_t jj = i + (uint32_t)cd.delta[s];
+                        j[t] = jj < v.N ? jj : i;
+                    } else { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
                     area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : load_stream<NT>(&v.larea[e]);
 #if SF3D_ASM_DIST_FROM_DESC == 2
                     /* chunk-uniform distance: the descriptor's ten distances were staged in LDS by the wave (one 80-byte load per chunk);
@@ -1399,8 +1404,9 @@ __device__ __forceinline__ void accept_links_row(const DevView& v, const sf3d_d2
     const ChunkDesc cd = v.cdesc[q];
     #pragma unroll
     for (int s = 0; s < SF3D_SLOTS; ++s) {
-        if (cd.kind[s] == CK_MIXED) j[s] = v.lto[(size_t)s * v.N + i];
-        else j[s] = i + cd.delta[s];
+        if (cd.kind[s] != CK_MIXED) j[s] = i + cd.delta[s];
+        else if ((cd.sweepUniform >> s) & 1u) { const uint32_t jj = i + (uint32_t)cd.delta[s]; j[s] = jj < v.N ? jj : i; }   /* a node without the link has a zero coefficient */
+        else j[s] = v.lto[(size_t)s * v.N + i];
     }
     if (v.compatCv != nullptr) {
         const double stale = v.compatCv[(size_t)v.compatCn[i] * v.N + i] * v.compatCv[i];
@@ -1862,6 +1868,12 @@ struct DeviceSolver::Impl {
         pGroupEnd();
     }
     void rccl_gather(hipStream_t st) { pAllGather(rcclMine, rcclGathered, 3, ncclDouble, comm, st); }
+    /* device slot of every (host slot, node): empty = identity.  Laterals of nodes with fewer links than their chunk's fullest node are
+     * moved to the slots where that node keeps the same neighbour offset (sync_to_device), so that a slot means one direction for the
+     * whole chunk; host arrays (HostModel, what the API reads and writes) stay in insertion order, the permutation is applied where
+     * per-link arrays cross the boundary (flow sums up and down, heat link fluxes down). */
+    std::vector<uint8_t> dslot;
+    std::vector<double> stage;             /* N x 10 staging area of those transfers */
     uint32_t connectGen = 0;               /* token of the window self-check */
     bool warnedShared = false;
     /* timing */
@@ -2002,6 +2014,69 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         std::vector<double> dist(NS, 0.), area(NS, 0.);
         std::vector<uint32_t> to(NS, 0u);
         std::atomic<bool> bad{false};
+        {   /* Slot alignment.  setNodeLink puts a node's k-th lateral link into slot 2 + k, so a node at the edge of a grid (fewer
+             * laterals) holds OTHER directions in its slots than its 63 chunk mates and the whole chunk falls back to per-lane link
+             * kinds and indices (two dependent round trips per group of links in the assembly instead of one: a quarter of the soil
+             * chunks of a 512-wide grid).  On the device such a node's laterals sit in the slots where the chunk's fullest node has the
+             * same neighbour offset and link kind, in the same relative order - the sums of a row are taken over the existing links in
+             * slot order, so every result keeps its bits.  Nodes that do not fit the pattern keep their own order. */
+            I.dslot.clear();
+            const char* re = getenv("SF3D_SLOT_ALIGN");
+            if (!(re && re[0] == '0')) {
+                std::vector<uint8_t> ds(NS);
+                for (int sl = 0; sl < SF3D_SLOTS; ++sl) std::memset(ds.data() + (size_t)sl * N, sl, N);
+                std::atomic<bool> moved{false};
+                const uint32_t nq = (N + SF3D_CHUNK - 1) / SF3D_CHUNK;
+                auto lateral_kind = [&](uint32_t i, int sl) -> int {      /* 0: no lateral link in host slot sl */
+                    if (sl - 2 >= m.nLat[i] || m.ltype[sl][i] == SF3D_LINK_NONE) return 0;
+                    const bool si = i >= ns, sj = m.lto[sl][i] >= ns;
+                    return (si && sj) ? 1 + (m.ltype[sl][i] == SF3D_LINK_LATERAL ? 0 : 1) : ((!si && !sj) ? 3 : 4);
+                };
+                parallel_for(nq, [&](uint32_t qa, uint32_t qb) {
+                    for (uint32_t q = qa; q < qb; ++q) {
+                        const uint32_t i0 = q * SF3D_CHUNK, i1 = (i0 + SF3D_CHUNK < N) ? i0 + SF3D_CHUNK : N;
+                        /* the pattern: the node with the most laterals, if they fill its slots 2 .. 2 + n - 1 */
+                        uint32_t tmpl = i0; int tn = -1;
+                        for (uint32_t i = i0; i < i1; ++i) {
+                            int n = 0; bool dense = true;
+                            for (int sl = 2; sl < SF3D_SLOTS; ++sl) { const bool on = lateral_kind(i, sl) != 0; if (on) { if (sl - 2 != n) dense = false; ++n; } }
+                            if (dense && n > tn) { tn = n; tmpl = i; }
+                        }
+                        if (tn <= 0) continue;
+                        int64_t td[SF3D_SLOTS]; int tk[SF3D_SLOTS];
+                        for (int p = 0; p < tn; ++p) { td[p] = (int64_t)m.lto[2 + p][tmpl] - (int64_t)tmpl; tk[p] = lateral_kind(tmpl, 2 + p); }
+                        for (uint32_t i = i0; i < i1; ++i) {
+                            if (i == tmpl) continue;
+                            uint8_t map[SF3D_SLOTS]; bool fits = true, differs = false; int p = 0;
+                            for (int sl = 2; sl < SF3D_SLOTS && fits; ++sl) {
+                                const int kk = lateral_kind(i, sl);
+                                map[sl] = (uint8_t)sl;
+                                if (!kk) continue;
+                                const int64_t dd = (int64_t)m.lto[sl][i] - (int64_t)i;
+                                while (p < tn && !(td[p] == dd && tk[p] == kk)) ++p;
+                                if (p >= tn) { fits = false; break; }
+                                map[sl] = (uint8_t)(2 + p); if (map[sl] != sl) differs = true;
+                                ++p;
+                            }
+                            if (!fits || !differs) continue;
+                            /* host slots without a link take the device slots that are left, so that the map stays a permutation */
+                            bool used[SF3D_SLOTS] = {false};
+                            for (int sl = 2; sl < SF3D_SLOTS; ++sl) if (lateral_kind(i, sl)) used[map[sl]] = true;
+                            int free_ = 2;
+                            for (int sl = 2; sl < SF3D_SLOTS; ++sl) {
+                                if (lateral_kind(i, sl)) continue;
+                                while (used[free_]) ++free_;
+                                map[sl] = (uint8_t)free_; used[free_] = true;
+                            }
+                            for (int sl = 2; sl < SF3D_SLOTS; ++sl) ds[(size_t)sl * N + i] = map[sl];
+                            moved = true;
+                        }
+                    }
+                });
+                if (moved) I.dslot.swap(ds);
+            }
+        }
+        const uint8_t* dslot = I.dslot.empty() ? nullptr : I.dslot.data();
         parallel_for(N, [&](uint32_t a, uint32_t b) {
             for (uint32_t i = a; i < b; ++i) {
                 const int nl = m.nLat[i];
@@ -2009,7 +2084,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (s >= 2 && s - 2 >= nl) continue;            /* lateral loop bound, cpusolver.cpp:360 */
                     if (m.ltype[s][i] == SF3D_LINK_NONE) continue;
                     const uint32_t j = m.lto[s][i];
-                    const size_t e = (size_t)s * N + i;
+                    const size_t e = (size_t)(dslot ? dslot[(size_t)s * N + i] : s) * N + i;
                     to[e] = j; area[e] = m.larea[s][i];
                     const bool si = i >= ns, sj = j >= ns;
                     if (si && sj) {
@@ -2060,7 +2135,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (any) ck = (all && same && fits) ? k0 : (uint8_t)CK_MIXED;
                     d.kind[s] = ck;
                     d.delta[s] = (ck != CK_NONE && ck != CK_MIXED) ? (int32_t)d0 : 0;
-                    if (ck == CK_MIXED && sameDelta && fits) { d.delta[s] = (int32_t)d0; d.sweepUniform |= (uint16_t)(1u << s); }   /* only the sweep looks at this */
+                    if (ck == CK_MIXED && sameDelta && fits) { d.delta[s] = (int32_t)d0; d.sweepUniform |= (uint16_t)(1u << s); }
                     if (any) {                                   /* one interface area for the whole chunk? */
                         bool first = true, uni = true; double a0 = 0.;
                         for (uint32_t i = i0; i < i1 && uni; ++i) {
@@ -2533,8 +2608,18 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
     }
     if (m.flowSumsDirty) {
         HIP_TRY(hipMemcpyAsync(v.bflowSum, m.bflowSum.data(), N * 8, hipMemcpyHostToDevice, I.stream));
-        for (int s = 0; s < SF3D_SLOTS; ++s)
-            HIP_TRY(hipMemcpyAsync(v.lflowSum + (size_t)s * N, m.lflowSum[s].data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        if (I.dslot.empty()) {
+            for (int s = 0; s < SF3D_SLOTS; ++s)
+                HIP_TRY(hipMemcpyAsync(v.lflowSum + (size_t)s * N, m.lflowSum[s].data(), N * 8, hipMemcpyHostToDevice, I.stream));
+        } else {                                   /* insertion order -> device slots */
+            I.stage.resize(NS);
+            for (int s = 0; s < SF3D_SLOTS; ++s) {
+                const uint8_t* d = I.dslot.data() + (size_t)s * N; const double* src = m.lflowSum[s].data();
+                for (uint32_t i = 0; i < N; ++i) I.stage[(size_t)d[i] * N + i] = src[i];
+            }
+            HIP_TRY(hipMemcpyAsync(v.lflowSum, I.stage.data(), NS * 8, hipMemcpyHostToDevice, I.stream));
+            HIP_TRY(hipStreamSynchronize(I.stream));
+        }
         m.flowSumsDirty = false;
     }
     if (v.heat.on) {
@@ -2582,9 +2667,19 @@ sf3d_error_t DeviceSolver::fetch_flows(HostModel& m)
     if (I.stream2) { HIP_TRY(hipStreamSynchronize(I.stream2)); I.linksPending[0] = I.linksPending[1] = false; }     /* link flow sums of the last step */
     HIP_TRY(hipMemcpyAsync(m.bflowSum.data(), I.v.bflowSum, N * 8, hipMemcpyDeviceToHost, I.stream));
     HIP_TRY(hipMemcpyAsync(m.bflowRate.data(), I.v.bflowRate, N * 8, hipMemcpyDeviceToHost, I.stream));
-    for (int s = 0; s < SF3D_SLOTS; ++s)
-        HIP_TRY(hipMemcpyAsync(m.lflowSum[s].data(), I.v.lflowSum + (size_t)s * N, N * 8, hipMemcpyDeviceToHost, I.stream));
-    HIP_TRY(hipStreamSynchronize(I.stream));
+    if (I.dslot.empty()) {
+        for (int s = 0; s < SF3D_SLOTS; ++s)
+            HIP_TRY(hipMemcpyAsync(m.lflowSum[s].data(), I.v.lflowSum + (size_t)s * N, N * 8, hipMemcpyDeviceToHost, I.stream));
+        HIP_TRY(hipStreamSynchronize(I.stream));
+    } else {                                       /* device slots -> insertion order */
+        I.stage.resize(N * SF3D_SLOTS);
+        HIP_TRY(hipMemcpyAsync(I.stage.data(), I.v.lflowSum, N * SF3D_SLOTS * 8, hipMemcpyDeviceToHost, I.stream));
+        HIP_TRY(hipStreamSynchronize(I.stream));
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            const uint8_t* d = I.dslot.data() + (size_t)s * N; double* dst = m.lflowSum[s].data();
+            for (size_t i = 0; i < N; ++i) dst[i] = I.stage[(size_t)d[i] * N + i];
+        }
+    }
     m.hostStaleFlows = false;
     return SF3D_OK;
 }
@@ -2608,8 +2703,19 @@ sf3d_error_t DeviceSolver::fetch_link_flux(HostModel& m, int type)
     if (type < 0 || type >= SF3D_FLUX_TYPES || !I.v.heat.on || !I.v.heat.lflux[type]) return SF3D_MISSING_DATA_ERROR;
     const size_t NS = (size_t)m.N * SF3D_SLOTS;
     m.lfluxCache[type].resize(NS);
-    HIP_TRY(hipMemcpyAsync(m.lfluxCache[type].data(), I.v.heat.lflux[type], NS * 8, hipMemcpyDeviceToHost, I.stream));
-    HIP_TRY(hipStreamSynchronize(I.stream));
+    if (I.dslot.empty()) {
+        HIP_TRY(hipMemcpyAsync(m.lfluxCache[type].data(), I.v.heat.lflux[type], NS * 8, hipMemcpyDeviceToHost, I.stream));
+        HIP_TRY(hipStreamSynchronize(I.stream));
+    } else {                                       /* device slots -> insertion order */
+        I.stage.resize(NS);
+        HIP_TRY(hipMemcpyAsync(I.stage.data(), I.v.heat.lflux[type], NS * 8, hipMemcpyDeviceToHost, I.stream));
+        HIP_TRY(hipStreamSynchronize(I.stream));
+        const size_t N = m.N;
+        for (int s = 0; s < SF3D_SLOTS; ++s) {
+            const uint8_t* d = I.dslot.data() + (size_t)s * N; double* dst = m.lfluxCache[type].data() + (size_t)s * N;
+            for (size_t i = 0; i < N; ++i) dst[i] = I.stage[(size_t)d[i] * N + i];
+        }
+    }
     m.lfluxValid[type] = true;
     return SF3D_OK;
 }
