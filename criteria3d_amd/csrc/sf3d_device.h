@@ -58,7 +58,7 @@ struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double clay, organicMatter;   /* heat only */
 };
 
-/* per-chunk link descriptor (224 bytes, fetched through the scalar path once per chunk) */
+/* per-chunk link descriptor (240 bytes, fetched through the scalar path once per chunk) */
 struct ChunkDesc {
     int32_t delta[SF3D_SLOTS];          /* j - i when kind[s] is a uniform link kind, else 0 */
     uint8_t kind[SF3D_SLOTS];           /* CK_NONE | LK_* (uniform) | CK_MIXED */
@@ -70,8 +70,11 @@ struct ChunkDesc {
                                          * slots): neither the sweep nor the assembly reads lto there */
     uint16_t distUniform;               /* bit s: every link of slot s in the chunk has the link distance dist[s] */
     uint8_t soilUniform;                /* 1: a soil-only chunk whose slots are all either empty or one uniform soil-soil link kind with uniform offset,
-                                         * area and distance (interior of a regular grid below layer 1): k_assemble's scalar-geometry path */
+                                         * area and distance (interior of a regular grid below layer 1): k_assemble_uniform's scalar-geometry rows;
+                                         * 2: the same except that some nodes lack some of the links (row ends: DevView::lmask says which) */
     uint8_t pad1[5];
+    uint8_t ukind[SF3D_SLOTS];          /* the one link kind of the nodes that HAVE slot s (= kind[s] when that is uniform; CK_MIXED if they differ) */
+    uint8_t pad2[6];
     double area[SF3D_SLOTS];            /* (cell size and layer thickness make it constant over regular grids) */
     double dist[SF3D_SLOTS];
 };
@@ -252,6 +255,7 @@ struct DevView {
     /* the same chunks in the order the assembly walks them: [0, nListSurf) surface (k_assemble), [nListSurf, nAsmGen) soil chunks
      * that need the general row code (k_assemble), [nAsmGen, nList) soil chunks with ChunkDesc::soilUniform (k_assemble_uniform) */
     const uint32_t* asmList; uint32_t nAsmGen, nbAsmU;
+    const uint16_t* lmask;      /* bit s: the node has a link in (device) slot s */
     uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once
                                            per approximation (k_post) instead of once per sweep, off the critical path (SF3D_HALO_DIRECT=0: old way) */
     uint32_t ntStream;                  /* 1: streamed-once arrays (coefficients, link geometry, flow sums) bypass the caches

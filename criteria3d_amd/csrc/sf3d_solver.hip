@@ -1277,19 +1277,21 @@ __global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASMU_WAVES) k_assemble_unifor
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc& cd = v.cdesc[q];                               /* wave-uniform address: scalar loads, field by field */
         const double Hoi = Xh[i], Ki = v.K[i], Ci = v.C[i], flowi = v.flow[i];
+        const uint32_t has = (cd.soilUniform == 2) ? (uint32_t)v.lmask[i] : 0x3FFu;      /* row ends: which of the chunk's links this node has */
         double kj[SF3D_SLOTS], k[SF3D_SLOTS];
         #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) kj[s] = (cd.kind[s] != CK_NONE) ? v.K[i + cd.delta[s]] : 0.;
+        for (int s = 0; s < SF3D_SLOTS; ++s) kj[s] = (cd.ukind[s] != CK_NONE && ((has >> s) & 1u)) ? v.K[i + cd.delta[s]] : 0.;
         double sum = 0.;
         #pragma unroll
         for (int o = 0; o < SF3D_SLOTS; ++o) {
             const uint32_t s = order[o];
             double ks = 0.;
-            if (cd.kind[s] == LK_SOIL_LAT) {                             /* redistribution, water.cpp:542-562 */
+            if (cd.ukind[s] == LK_SOIL_LAT) {                            /* redistribution, water.cpp:542-562 */
                 const double ki = Ki * lvRatio, kn = kj[s] * lvRatio;
-                ks = qdiv(mean_of(ki, kn, meanType) * cd.area[s], cd.dist[s]);
-            } else if (cd.kind[s] == LK_SOIL_VERT)
-                ks = qdiv(mean_of(Ki, kj[s], meanType) * cd.area[s], cd.dist[s]);
+                if ((has >> s) & 1u) ks = qdiv(mean_of(ki, kn, meanType) * cd.area[s], cd.dist[s]);
+            } else if (cd.ukind[s] == LK_SOIL_VERT) {
+                if ((has >> s) & 1u) ks = qdiv(mean_of(Ki, kj[s], meanType) * cd.area[s], cd.dist[s]);
+            }
             k[s] = ks;
             sum += ks;
             __builtin_amdgcn_sched_barrier(0);
@@ -2134,6 +2136,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     uint8_t ck = CK_NONE;
                     if (any) ck = (all && same && fits) ? k0 : (uint8_t)CK_MIXED;
                     d.kind[s] = ck;
+                    d.ukind[s] = any ? ((same && fits) ? k0 : (uint8_t)CK_MIXED) : (uint8_t)CK_NONE;
                     d.delta[s] = (ck != CK_NONE && ck != CK_MIXED) ? (int32_t)d0 : 0;
                     if (ck == CK_MIXED && sameDelta && fits) { d.delta[s] = (int32_t)d0; d.sweepUniform |= (uint16_t)(1u << s); }
                     if (any) {                                   /* one interface area for the whole chunk? */
@@ -2156,12 +2159,14 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     }
                 }
                 {   /* scalar-geometry path of k_assemble: full 64-node soil chunk, every slot empty or uniform soil-soil */
-                    bool su = d.rowType == 1 && i1 - i0 == SF3D_CHUNK;
+                    bool su = d.rowType == 1 && i1 - i0 == SF3D_CHUNK, partial = false;
                     for (int s = 0; s < SF3D_SLOTS && su; ++s) {
                         if (d.kind[s] == CK_NONE) continue;
-                        su = (d.kind[s] == LK_SOIL_VERT || d.kind[s] == LK_SOIL_LAT) && ((d.areaUniform >> s) & 1u) && ((d.distUniform >> s) & 1u);
+                        if (d.kind[s] == CK_MIXED) partial = true;      /* same kind and offset wherever the link exists (ukind, sweepUniform), some nodes without it */
+                        su = (d.ukind[s] == LK_SOIL_VERT || d.ukind[s] == LK_SOIL_LAT) && (d.kind[s] != CK_MIXED || ((d.sweepUniform >> s) & 1u))
+                             && ((d.areaUniform >> s) & 1u) && ((d.distUniform >> s) & 1u);
                     }
-                    d.soilUniform = su ? 1 : 0;
+                    d.soilUniform = su ? (partial ? 2 : 1) : 0;
                 }
                 cdesc[q] = d;
             }
@@ -2308,6 +2313,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
             auto blocks = [&](uint32_t chunks) { uint32_t b = (chunks + per - 1) / per; if (b > SF3D_MAX_BLOCKS) b = SF3D_MAX_BLOCKS; return b; };
             v.nbSoil = blocks(v.nAsmGen - v.nListSurf);
+            if (const char* be = getenv("SF3D_ASM_SOIL_BLOCKS")) { const uint32_t nb = (uint32_t)atoi(be); if (nb > 0 && nb < v.nbSoil) v.nbSoil = nb; }   /* tuning */
             v.nbAsmU = blocks(v.nList - v.nAsmGen);
         }
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness, *larea, *ldist;
@@ -2563,6 +2569,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         HIP_TRY(hipMemcpy(cls, m.cls.data(), N * 2, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lto, to.data(), NS * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(lkind, kind.data(), NS, hipMemcpyHostToDevice));
+        {   std::vector<uint16_t> mask(N, 0);
+            for (int sl = 0; sl < SF3D_SLOTS; ++sl) { const uint8_t* kk = kind.data() + (size_t)sl * N; for (uint32_t i = 0; i < N; ++i) if (kk[i] != LK_NONE) mask[i] |= (uint16_t)(1u << sl); }
+            uint16_t* dm; HIP_TRY(dev_alloc(I.allocs, dm, N));
+            HIP_TRY(hipMemcpy(dm, mask.data(), (size_t)N * 2, hipMemcpyHostToDevice));
+            v.lmask = dm; }
         HIP_TRY(hipMemcpy(larea, area.data(), NS * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ldist, dist.data(), NS * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(dcdesc, cdesc.data(), cdesc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
@@ -3153,9 +3164,11 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         HIP_TRY(hipStreamCreateWithFlags(&I.stream3, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&I.evFork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&I.evJoin, hipEventDisableTiming));
     }
+    static const bool asmNtOff = getenv("SF3D_ASM_NT") && getenv("SF3D_ASM_NT")[0] == '0';      /* tuning: cacheable stores of the rows */
+    const bool asmNT = v.ntStream && !asmNtOff;
     auto launch_uniform_rows = [&] {
         if (v.nAsmGen >= v.nList) return;
-        if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
+        if (asmNT) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
         else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, st, v);
     };
     auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) {
@@ -3163,23 +3176,23 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
-            else if (fuse0) timed(KID_ASSEMBLE, [&] { if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (fuse0) timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (concurrentRows) timed(KID_ASSEMBLE, [&] {
                 /* the chunk-uniform soil rows on a stream of their own NEXT TO the general rows (fork after k_props, join before the Courant
                  * decision, which therefore is a kernel of its own here: the stage must not move while either kernel is running) */
                 hipEventRecord(I.evFork, st);
                 hipStreamWaitEvent(I.stream3, I.evFork, 0);
-                if (v.ntStream) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, I.stream3, v);
+                if (asmNT) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, I.stream3, v);
                 else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, I.stream3, v);
                 hipEventRecord(I.evJoin, I.stream3);
-                if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
+                if (asmNT) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
                 else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
                 hipStreamWaitEvent(st, I.evJoin, 0);
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             });
-            else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
-                timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (v.ntStream) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (asmNT) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 1); I.rccl_gather(st); }
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
