@@ -64,6 +64,12 @@ class Model:
     cell_area: float = 100.0
     shape: tuple = ()
     meta: dict = field(default_factory=dict)
+    # project models (criteria3d_amd/project3d.py): several horizons per soil, several surface classes, a pond per cell
+    horizon_index: np.ndarray | None = None     # per soil node: horizon of `soil_index` (None: horizon 0)
+    soil_table: list | None = None              # [(soil, horizon, setSoilProperties arguments)] (None: `soils`, horizon 0)
+    surface_index: np.ndarray | None = None     # per surface node: surface class (None: class 0)
+    surface_roughness: list | None = None       # Manning roughness per surface class (None: [roughness])
+    pond_node: np.ndarray | None = None         # per surface node: pond [m] (None: `pond` everywhere)
 
 
 def splitmix64(v: np.ndarray) -> np.ndarray:
@@ -233,7 +239,11 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
     else:
         sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, int(heat.water), 1, 0, heat.save_mode), "initialize")
         sf.check(sf.lib.sf3d_initialize_heat_flag(heat.save_mode, int(heat.advection), int(heat.latent)), "initialize_heat_flag")
-    sf.check(sf.lib.sf3d_set_surface_properties(0, m.roughness), "set_surface_properties")
+    for k, rough in enumerate(m.surface_roughness if m.surface_roughness is not None else [m.roughness]):
+        sf.check(sf.lib.sf3d_set_surface_properties(k, rough), "set_surface_properties")
+    if m.soil_table is not None:
+        for soil, horizon, args in m.soil_table:
+            sf.check(sf.lib.sf3d_set_soil_properties(soil, horizon, *args), f"set_soil_properties({soil}, {horizon})")
     for k, s in enumerate(m.soils):
         sf.check(sf.lib.sf3d_set_soil_properties(k, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"],
                                                  s["theta_r"], s["theta_s"], s["ksat"], s["L"],
@@ -241,10 +251,10 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
     sf.set_nodes_bulk(0, m.x, m.y, m.z, m.size, m.is_surface, m.btype, m.bslope, m.barea)
     sf.set_links_bulk(m.link_node, m.link_to, m.link_dir, m.link_area)
     if m.ns > 0:
-        sf.set_surface_bulk(0, np.zeros(m.ns, np.uint16))
-        sf.set_pond_bulk(0, np.full(m.ns, m.pond))
+        sf.set_surface_bulk(0, m.surface_index if m.surface_index is not None else np.zeros(m.ns, np.uint16))
+        sf.set_pond_bulk(0, m.pond_node if m.pond_node is not None else np.full(m.ns, m.pond))
     if m.n > m.ns:
-        sf.set_soil_bulk(m.ns, m.soil_index, np.zeros(m.n - m.ns, np.uint16))
+        sf.set_soil_bulk(m.ns, m.soil_index, m.horizon_index if m.horizon_index is not None else np.zeros(m.n - m.ns, np.uint16))
     sf.check(sf.lib.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, m.lv_ratio),
              "set_hydraulic_properties")
     sf.check(sf.lib.sf3d_set_numerical_parameters(*m.numerics), "set_numerical_parameters")
