@@ -42,11 +42,18 @@ import numpy as np  # noqa: E402
 
 WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
              "C5S": (519, 1208, 15),      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
-             "C5": (519, 1208, 15)}       # the Ravone DEM itself (tests/golden/ravone_dem_519x1208.npz, 422 282 valid cells of 4 m)
+             "C5": (519, 1208, 14),       # BASELINE config 5: the Ravone PROJECT (DEM + soil map + soil DB + land use, criteria3d_amd/project3d.py)
+             "C5DEM": (519, 1208, 15)}    # round-2 stand-in: the Ravone DEM with synthetic soils (kept for comparison with round-2 numbers)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes")
-# k_sweep_pair: two Jacobi iterations per launch, priced as the two sweeps it replaces (2 x 152 B/node)
-ALGO_BYTES = {"k_sweep": 152, "k_sweep_pair": 304, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
+# algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes"): what ONE launch has to move.
+# k_sweep_pair makes one pass for two Jacobi iterations: 80 coefficients + 40 index + 8 b + 8 z + 8 x + 8 x' + 8 x'' = 160 B/node
+# (the two single sweeps it replaces would move 2 x 152: reported separately as `equivalent_sweep_frac`, never as `frac`)
+ALGO_BYTES = {"k_sweep": 152, "k_sweep_pair": 160, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288,
+              "k_approx_patch": 441 - 84}
+EQUIVALENT_SWEEP_BYTES = {"k_sweep_pair": 2 * 152}
+# whole-step model of SURVEY.md 8d: bytes = N (B_J n_J + 441 n_A + 336 n_S + 117 n_R); with the paired sweep a Jacobi iteration
+# costs half a pass (80 B/node)
+B_APPROX, B_STEP, B_RESTORE = 441, 336, 117
 
 
 def log(*a):
@@ -143,13 +150,14 @@ def spawn_ranks(n, argv):
 def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0, threads=32):
     """Reference CPU/OpenMP path on a bounded sample: computeStep calls from the same initial
     state until `budget_s` seconds of CPU work are spent (at least one step)."""
+    from tests import checkers          # checker libraries (oracle/): this leg only
     kind, sf = "port", None
     try:
-        sf = capi.load_reference()
+        sf = checkers.load_reference()
         kind = "reference"
     except Exception as e:  # noqa: BLE001  (missing Qt on the box, or oracle/_ref not built)
         log(f"[bench] oracle/_ref not loadable ({e}); timing the oracle port instead")
-        sf = capi.load_oracle()
+        sf = checkers.load_oracle()
     # profiles/r01_cpu_baselines.json: on this class of host the reference's OpenMP path is fastest with
     # 16-32 threads (C4 hour 0: 12.6 s at 32, 17.3 s at 64) and collapses when every logical CPU is used
     # (256 threads: 50x slower), so the baseline uses `threads`, not os.cpu_count()
@@ -197,6 +205,7 @@ def main():
     ap.add_argument("--forcing", default="F20", choices=["F20", "F60"])
     ap.add_argument("--lineal", action="store_true", help="setUseLineal(true) with the device conjugate gradients (SF3D_LINEAL_DEVICE_CG=1) instead of Jacobi sweeps: not the headline path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f60", action="store_true", help="skip the C4 F60 hour-0 leg (runoff regime, SURVEY 8d)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events (no roofline object): batches replay from hipGraphs")
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
     ap.add_argument("--reps", type=int, default=0, help="repetitions of the timed region, each from the initial state (rewound, not rebuilt); the median is reported; 0 = at least 3 and as many as it takes to time 1.5 s (at most 15)")
@@ -256,6 +265,10 @@ def main():
     if args.workload == "C5S":
         model = cm.dem_model_fast(cm.synthetic_dem(ny, nx))
     elif args.workload == "C5":
+        from criteria3d_amd import project3d
+        model = project3d.project_model(project3d.load_project_fixture(ROOT / "tests" / "golden" / "ravone_project.npz"))
+        nz = model.shape[2]
+    elif args.workload == "C5DEM":
         from criteria3d_amd import esri
         model = cm.dem_model_fast(esri.load_dem_fixture(ROOT / "tests" / "golden" / "ravone_dem_519x1208.npz")[0])
     else:
@@ -356,15 +369,31 @@ def main():
         return
 
     work = {k: c1[k] - c0[k] for k in c1}
+    f60 = None
+    if world == 1 and args.workload == "C4" and args.forcing == "F20" and not args.heat and not args.lineal and not args.no_f60:
+        # "C4: F20 6 sim-h for the headline number plus F60 hour 0 only" - the runoff-regime figure, timed here so that it
+        # is on the driver's line: hour 0 of the 60 mm forcing from the initial state (76 steps incl. the Courant rejections), median of 3
+        f60_s, f60_work = [], None
+        for _ in range(3):
+            rewind()
+            torch.cuda.synchronize()
+            cb = sf.counters()
+            f60_s.append(run_hours(sf, cm, model, "F60", 1))
+            torch.cuda.synchronize()
+            ca = sf.counters()
+            f60_work = {k: ca[k] - cb[k] for k in ca}
+        t60 = sorted(f60_s)[1]
+        f60 = {"value": 1.0 / t60, "unit": "sim-h/s", "elapsed_s": t60, "ms_per_computeStep": t60 / max(1, f60_work["accepted"]) * 1e3,
+               "work": f60_work, "repeats_s": f60_s, "workload": "C4 512x512x20, forcing F60 (60 mm in hour 0), hour 0 from the initial state"}
     # dominant kernel by measured device time
     dom = max(stats, key=lambda k: stats[k][1]) if stats else None      # k_sweep unless --time-all-kernels finds another
     roofline = None
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs
     # of this same command, corrected per MI355X_MICROARCH.md: 2 x FETCH_SIZE + WRITE_SIZE); bench.py
     # cannot collect counters itself
-    traffic, traffic_source = None, None
+    traffic, traffic_source, run_traffic = None, None, None
     try:
-        for tag in ("r02_c", "r02_b", "r02_a", "r01_k"):
+        for tag in ("r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
             f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
             if not f.exists():
                 continue
@@ -372,6 +401,8 @@ def main():
             tuned = os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")
             if world == 1 and args.workload == "C4" and not tuned and dom in prof and "hbm_traffic_MB" in prof[dom]:
                 traffic = prof[dom]["hbm_traffic_MB"] * 1e6
+                if args.steps == prof.get("whole_run", {}).get("steps") and args.forcing == "F20":
+                    run_traffic = prof["whole_run"]["hbm_traffic_GB"] * 1e9
                 traffic_source = f"stored profile profiles/{f.name} (rocprofv3 --pmc passes of this command; not measured in this run)"
             break
     except Exception:  # noqa: BLE001
@@ -383,19 +414,29 @@ def main():
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         note = None
         if dom == "k_sweep_pair":
-            # one launch = two Jacobi sweeps: priced, as the contract says, at SURVEY 8d's 152 B/node per sweep x the two sweeps it
-            # performs.  The launch itself moves less - the coefficient stream is read once for both iterations - which is the point of
-            # the kernel and why the fraction can exceed 1; `pass_bytes_per_launch` / `pass_frac` price the one pass it really makes
-            # (80 coefficients + 40 index + 8 b + 8 z + 8 x + 8 x' + 8 x'' = 160 B/node)
-            note = "two Jacobi sweeps per launch priced at 2 x 152 B/node; the pass itself moves 160 B/node (pass_frac)"
+            note = ("one pass = two Jacobi iterations: `frac` prices the 160 B/node the pass moves; `equivalent_sweep_frac` prices the two "
+                    "single sweeps it replaces (2 x 152 B/node, SURVEY 8d) and is a speed-up measure, not a bandwidth fraction")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
-                    "note": note, "pass_bytes_per_launch": (160 * nodes if dom == "k_sweep_pair" else ALGO_BYTES[dom] * nodes),
-                    "pass_frac": ((160 if dom == "k_sweep_pair" else ALGO_BYTES[dom]) * nodes / avg_s / 1e9) / HBM_PEAK_GBS,
+                    "note": note,
+                    "equivalent_sweep_frac": (EQUIVALENT_SWEEP_BYTES[dom] * nodes / avg_s / 1e9 / HBM_PEAK_GBS) if dom in EQUIVALENT_SWEEP_BYTES else None,
                     "kernels": {k: {"launches": v[0], "total_ms": v[1],
-                                    "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 else None}
+                                    "GBps": (ALGO_BYTES[k] * (v[2] // world) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 and k in ALGO_BYTES else None}
                                 for k, v in stats.items()}}
+        # whole timed region (SURVEY 8d's model with the work counters of the run) over the median elapsed time
+        paired = stats.get("k_sweep_pair", (0,))[0] > 0
+        n_rank = model.n // world
+        b_j = 80 if paired else 152
+        step_bytes = n_rank * (b_j * work["sweeps"] + B_APPROX * work["approximations"] + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
+        survey_bytes = n_rank * (152 * work["sweeps"] + B_APPROX * work["approximations"] + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
+        roofline["step"] = {"bytes": step_bytes, "elapsed_s": elapsed, "achieved": step_bytes / elapsed / 1e9, "unit": "GB/s",
+                            "frac": step_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+                            "model": f"N ({b_j} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R) per rank, counters of the timed region"
+                                     + (" (a Jacobi iteration inside a paired pass costs 80 B/node)" if paired else ""),
+                            "survey_8d_bytes": survey_bytes, "survey_8d_frac": survey_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
+                            "traffic": run_traffic, "traffic_frac": (run_traffic / elapsed / 1e9 / HBM_PEAK_GBS) if run_traffic else None}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not args.heat:      # the baseline leg drives the water-only set-up
         try:
@@ -420,7 +461,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone DEM (DATA/DEM/DEM_Ravone.flt), 14 soil layers to 0.95 m"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
+        "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone project (DATA/PROJECT/Ravone: DEM, soil map, soil_ER_2021.db, land use; 13 soil layers to 0.95 m)", "C5DEM": "Ravone DEM with synthetic soils (round-2 stand-in)"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
                                f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)",
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI",
                    "work": work},
@@ -428,6 +469,9 @@ def main():
         "headline_6h": ({"value": 6.0 / elapsed_6h, "unit": "sim-h/s", "hours": "timed hours 0-5 (SURVEY.md 8d headline workload)",
                          "elapsed_s": elapsed_6h} if args.steps >= 6 and elapsed_6h > 0 else None),
         "inclusive_value": args.steps / elapsed_incl if elapsed_incl > 0 else None,
+        "value_timing": f"median of {reps} repetitions of the timed region; repetition 0 carries the HIP-event sampling of the dominant kernel "
+                        f"(every 8th computeStep launched eagerly), the others replay hipGraphs uninstrumented; repetition 0 took {rep_elapsed[0]:.4f} s",
+        "f60_hour0": f60,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -1,10 +1,9 @@
 """ctypes binding of the flat C ABI in include/sf3d.h.
 
-The same `SF3D` class drives any of the three shared libraries that export the ABI:
-the HIP product (`libsf3d_hip.so`), the CPU restatement (`oracle/libsf3d_oracle.so`) and the
-wrapped, unmodified reference (`oracle/_ref/libsf3d_ref.so`).  This module is plumbing only:
-it holds no numerical code.  Product code paths must use `load_product()`, which raises if the
-HIP library is missing - there is no CPU fallback.
+The `SF3D` class drives any shared library that exports the ABI; this package only ever loads the HIP product
+(`libsf3d_hip.so`, `load_product()`, which raises if it is missing - there is no CPU fallback).  The loaders of the
+checkers (the CPU restatement and the wrapped reference under oracle/) live in tests/checkers.py: test infrastructure.
+This module is plumbing only: it holds no numerical code.
 """
 from __future__ import annotations
 
@@ -16,9 +15,6 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 PRODUCT_LIB = Path(os.environ.get("SF3D_PRODUCT_LIB", ROOT / "criteria3d_amd" / "csrc" / "libsf3d_hip.so"))
-ORACLE_LIB = ROOT / "oracle" / "libsf3d_oracle.so"
-REFERENCE_LIB = ROOT / "oracle" / "_ref" / "libsf3d_ref.so"
-QT_CORE = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))
 
 # --- enums (include/sf3d.h) ---------------------------------------------------------------
 OK, INDEX_ERROR, MEMORY_ERROR, TOPOGRAPHY_ERROR, BOUNDARY_ERROR, MISSING_DATA_ERROR, \
@@ -335,29 +331,3 @@ def load_product() -> SF3D:
         raise SF3DError(f"{PRODUCT_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
                         "there is no CPU fallback for the product path")
     return SF3D(PRODUCT_LIB)
-
-
-def load_oracle() -> SF3D:
-    """CPU restatement (TEST INFRASTRUCTURE: tests/, smoke(), bench cpu_baseline only)."""
-    return SF3D(ORACLE_LIB)
-
-
-def load_reference() -> SF3D:
-    """The wrapped, unmodified reference (TEST INFRASTRUCTURE; built by oracle/Makefile `ref`)."""
-    if QT_CORE.exists():
-        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)   # linked by soname, deliberately not on the rpath
-    return SF3D(REFERENCE_LIB)
-
-
-def load_reference_ndebug() -> SF3D:
-    """The same unmodified sources built with -DNDEBUG (oracle/Makefile `ref-ndebug`): golden vectors with Urban / Road nodes."""
-    if QT_CORE.exists():
-        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)
-    return SF3D(REFERENCE_LIB.with_name("libsf3d_ref_ndebug.so"))
-
-
-def load_reference_tuned() -> SF3D:
-    """The same unmodified sources built -O3 -march=x86-64-v3 (oracle/Makefile `ref-tuned`): CPU baseline timing only."""
-    if QT_CORE.exists():
-        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)
-    return SF3D(REFERENCE_LIB.with_name("libsf3d_ref_tuned.so"))

@@ -2785,8 +2785,10 @@ sf3d_error_t DeviceSolver::dist_export(HostModel& m, const ParamsHost& p, DistBl
     for (int r = 0; r < world_; ++r) { out->recvOff[r] = I.hostDist.recvOff[r]; out->recvCount[r] = I.hostDist.recvCount[r]; }
     if (hipDeviceGetPCIBusId(out->pciBusId, (int)sizeof(out->pciBusId), I.device) != hipSuccess) out->pciBusId[0] = 0;
     out->generation = ++I.connectGen;
-    {   const char* xe = getenv("SF3D_EXCHANGE");
-        if (rank_ == 0 && !(xe && std::strcmp(xe, "ipc") == 0) && I.load_rccl()) {
+    {   /* the communicator id only when the RCCL exchange was asked for: ncclGetUniqueId starts RCCL's bootstrap root (listener thread and
+         * socket), which the default window path has no use for */
+        const char* xe = getenv("SF3D_EXCHANGE");
+        if (rank_ == 0 && xe && std::strcmp(xe, "rccl") == 0 && I.load_rccl()) {
             ncclUniqueId id;
             if (I.pGetUniqueId(&id) == ncclSuccess) { static_assert(sizeof(id) <= sizeof(out->ncclId), "ncclUniqueId size"); std::memcpy(out->ncclId, &id, sizeof(id)); }
         }
@@ -2870,11 +2872,12 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
     std::snprintf(distWhy_, sizeof(distWhy_), "%s", forceRccl ? "SF3D_EXCHANGE=rccl" : why);
     I.rcclDistinct = distinct;
     std::memcpy(I.rcclId, all[0].ncclId, sizeof(I.rcclId));
-    connected_ = distStatus_ == 0;        /* a launcher that never calls dist_finalize gets the windows if they work */
+    connected_ = false;                   /* the ranks' common decision comes with sf3d_dist_finalize: one rank whose windows failed while the
+                                           * others' passed must not leave the others spinning in the in-kernel exchange */
     return SF3D_OK;
 }
 
-/* the common decision of all ranks: keep the windows (all passed) or exchange over RCCL (some rank's did not, or SF3D_EXCHANGE=rccl) */
+/* the common decision of all ranks: keep the windows (all passed), or - only with SF3D_EXCHANGE=rccl - exchange over RCCL */
 sf3d_error_t DeviceSolver::dist_finalize(bool useRccl)
 {
     if (world_ == 1) { connected_ = true; return SF3D_OK; }
@@ -2888,6 +2891,14 @@ sf3d_error_t DeviceSolver::dist_finalize(bool useRccl)
     HIP_TRY(hipSetDevice(I.device));
     DistView& d = I.hostDist;
     const char* xe = getenv("SF3D_EXCHANGE");
+    if (!(xe && std::strcmp(xe, "rccl") == 0)) {
+        /* The RCCL exchange is opt-in: it has not run on hardware yet (its collectives are queued unconditionally inside look-ahead
+         * batches and have no bounded wait), so a failed window check is a hard error on every rank instead of a silent switch */
+        snprintf(err_, sizeof(err_), "rank %d: the window exchange failed its self-check on some rank (%.150s); the RCCL exchange is opt-in (SF3D_EXCHANGE=rccl)",
+                 rank_, distWhy_[0] ? distWhy_ : "this rank's windows passed");
+        fatal_ = true;
+        return SF3D_SOLVER_ERROR;
+    }
     bool haveId = false;
     for (size_t k = 0; k < sizeof(I.rcclId); ++k) if (I.rcclId[k]) haveId = true;
     if ((xe && std::strcmp(xe, "ipc") == 0) || !I.rcclDistinct || !haveId || !I.load_rccl()) {

@@ -370,9 +370,10 @@ sf3d_error_t sf3d_dist_export(void* blob_out);
 sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
 /* Which exchange: sf3d_dist_connect opens the peers' windows and checks them (one value through every window, both ways, bounded).
  * sf3d_dist_status() then says what THIS rank found: 0 = its windows work, 1 = they do not (or SF3D_EXCHANGE=rccl asks for RCCL).
- * The launcher all-gathers that one value and calls sf3d_dist_finalize(any rank said 1) on every rank: 0 keeps the windows, 1 joins
- * the RCCL communicator whose id rank 0 put into its blob (collective: ncclCommInitRank) and moves halos with ncclSend/ncclRecv and the
- * partial sums with ncclAllGather.  Launchers that skip the two calls get the windows, or an error at the first step if they failed. */
+ * The launcher all-gathers that one value and calls sf3d_dist_finalize(any rank said 1) on every rank - REQUIRED: the model is not
+ * connected before it.  0 keeps the windows.  1 is an error on every rank (some rank's windows failed) unless SF3D_EXCHANGE=rccl opted
+ * into the RCCL exchange: then all ranks join the communicator whose id rank 0 put into its blob (collective: ncclCommInitRank) and
+ * move halos with ncclSend/ncclRecv and the partial sums with ncclAllGather (coded, not yet run on hardware). */
 int          sf3d_dist_status(void);
 sf3d_error_t sf3d_dist_finalize(int use_rccl);
 /* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */

@@ -1,7 +1,8 @@
 import sys; sys.path.insert(0, "/root/repo")
 import numpy as np
 from criteria3d_amd import capi, catchment as cm
-g, o = capi.load_product(), capi.load_oracle()
+from tests import checkers
+g, o = capi.load_product(), checkers.load_oracle()
 m = cm.with_heat_surface(cm.dem_model(np.load('/root/repo/tests/golden/ravone_dem_window_72x72.npy')))
 heat = cm.Heat(save_mode=0)
 for sf in (g, o):

@@ -2,12 +2,13 @@
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 from criteria3d_amd import capi, catchment
+from tests import checkers
 
 which = sys.argv[1] if len(sys.argv) > 1 else "reference"
 water = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 adv = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lat = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-sf = {"reference": capi.load_reference, "oracle": capi.load_oracle}[which]()
+sf = {"reference": checkers.load_reference, "oracle": checkers.load_oracle}[which]()
 sf.lib.sf3d_reset_solver_state()
 m = catchment.column_model(22, 0.05, 1.0)
 L = sf.lib

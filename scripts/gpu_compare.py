@@ -5,9 +5,10 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from criteria3d_amd import capi, catchment as cm
+from tests import checkers
 
 def compare(m, forcing, hours, max_steps=None):
-    gpu, ora = capi.load_product(), capi.load_oracle()
+    gpu, ora = capi.load_product(), checkers.load_oracle()
     for sf in (gpu, ora):
         sf.lib.sf3d_reset_solver_state()
         cm.build(sf, m, threads=(16 if m.n < 200000 else 32))

@@ -1,0 +1,41 @@
+"""Loaders of the CHECKERS (test infrastructure): the CPU restatement oracle/libsf3d_oracle.so and the wrapped, unmodified
+reference oracle/_ref/libsf3d_ref*.so.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use this module;
+the product package (criteria3d_amd/) holds no reference to anything under oracle/."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+from criteria3d_amd.capi import SF3D
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_LIB = ROOT / "oracle" / "libsf3d_oracle.so"
+REFERENCE_LIB = ROOT / "oracle" / "_ref" / "libsf3d_ref.so"
+QT_CORE = Path(os.environ.get("SF3D_QT_CORE", "/opt/conda/lib/libQt5Core.so.5"))
+
+
+def load_oracle() -> SF3D:
+    """CPU restatement of the reference algorithm (oracle/sf3d_oracle.cpp)."""
+    return SF3D(ORACLE_LIB)
+
+
+def _reference(name: str) -> SF3D:
+    if QT_CORE.exists():
+        C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)   # linked by soname, deliberately not on the rpath
+    return SF3D(REFERENCE_LIB.with_name(name))
+
+
+def load_reference() -> SF3D:
+    """The wrapped, unmodified reference (built by oracle/Makefile `ref`)."""
+    return _reference("libsf3d_ref.so")
+
+
+def load_reference_ndebug() -> SF3D:
+    """The same unmodified sources built with -DNDEBUG (oracle/Makefile `ref-ndebug`): golden vectors with Urban / Road nodes."""
+    return _reference("libsf3d_ref_ndebug.so")
+
+
+def load_reference_tuned() -> SF3D:
+    """The same unmodified sources built -O3 -march=x86-64-v3 (oracle/Makefile `ref-tuned`): CPU baseline timing only."""
+    return _reference("libsf3d_ref_tuned.so")

@@ -15,10 +15,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
-    from criteria3d_amd import build, capi
-    if not capi.ORACLE_LIB.exists():
+    from criteria3d_amd import build
+    from tests import checkers
+    if not checkers.ORACLE_LIB.exists():
         build.build_oracle(with_reference=False)
-    return capi.load_oracle()
+    return checkers.load_oracle()
 
 
 @pytest.fixture(scope="session")

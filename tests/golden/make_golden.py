@@ -17,6 +17,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 from criteria3d_amd import capi, catchment as cm  # noqa: E402
+from tests import checkers
 from tests.scenarios import REFERENCE_VARIANT, SCENARIOS, run_scenario  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
@@ -33,7 +34,7 @@ def main():
             subprocess.run([sys.executable, __file__, name], check=True)
         return
     name = names[0]
-    ref = capi.load_reference_ndebug() if REFERENCE_VARIANT.get(name) == "ndebug" else capi.load_reference()
+    ref = checkers.load_reference_ndebug() if REFERENCE_VARIANT.get(name) == "ndebug" else checkers.load_reference()
     assert ref.backend == "reference"
     trace = run_scenario(ref, name, threads=1)
     np.savez_compressed(OUT / f"{name}.npz", **trace)

@@ -8,16 +8,17 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from criteria3d_amd import capi  # noqa: E402
+from tests import checkers
 from tests.scenarios import run_scenario  # noqa: E402
 
 
 def main(name):
     try:
-        ref = capi.load_reference()
+        ref = checkers.load_reference()
     except Exception as e:  # noqa: BLE001
         print(f"SKIP {e}")
         return 77
-    a = run_scenario(capi.load_oracle(), name, threads=1)
+    a = run_scenario(checkers.load_oracle(), name, threads=1)
     b = run_scenario(ref, name, threads=1)
     def same(k):
         x, y = np.asarray(a[k]), np.asarray(b[k])

@@ -134,6 +134,26 @@ def ravone_window(sf, threads=1):
     return _hours(sf, m, [(15.0, None, True), (15.0, 300, False), (0.0, 300, True)], threads)
 
 
+RAVONE_PROJECT_WINDOW = (1000, 1048, 352, 400)
+
+
+def ravone_project_model(window=RAVONE_PROJECT_WINDOW):
+    """BASELINE config 5 as specified, cut to a window: DEM + soil map + soil database + land use of DATA/PROJECT/Ravone
+    (tests/golden/ravone_project.npz) through criteria3d_amd.project3d.project_model"""
+    from pathlib import Path
+    from criteria3d_amd import project3d as p3
+    inp = p3.load_project_fixture(Path(__file__).resolve().parent / "golden" / "ravone_project.npz")
+    return p3.project_model(p3.window(inp, *window) if window is not None else inp)
+
+
+def ravone_project_window(sf, threads=1):
+    """48 x 48 window of the Ravone PROJECT where four soils of soilMap_Ravone.flt meet (BSC 0.5 m deep: short columns; CRA,
+    FRN, OSP), 14 % outside the catchment: multi-horizon soils out of the 1 688 rows pushed through setSoilProperties,
+    ponds from the slope, runoff outlets from the aspect map, the application's numerical parameters (accuracy 2)."""
+    m = ravone_project_model()
+    return _hours(sf, m, [(25.0, None, True), (0.0, 200, True)], threads)
+
+
 def surface_only(sf, threads=1):
     """no soil at all: 3 mm of ponded water runs off a tilted sheet, then 10 mm of rain"""
     m = cm.surface_only_model()
@@ -319,6 +339,7 @@ SCENARIOS = {
     "ragged_arithmetic_vg": ragged_arithmetic_vg,
     "ragged_geometric": ragged_geometric,
     "ravone_window": ravone_window,
+    "ravone_project_window": ravone_project_window,
     "surface_only": surface_only,
     "soil_only": soil_only,
     "heat_column_conduction": heat_column_conduction,

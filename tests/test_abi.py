@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from criteria3d_amd import build, capi
+from tests import checkers
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -37,7 +38,7 @@ def test_product_library_exports_every_declared_symbol(product):
 
 
 def test_oracle_library_exports_every_declared_symbol(oracle):
-    assert not set(declared_symbols()) - exported(capi.ORACLE_LIB)
+    assert not set(declared_symbols()) - exported(checkers.ORACLE_LIB)
     assert oracle.backend == "oracle"
 
 

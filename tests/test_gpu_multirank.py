@@ -125,7 +125,20 @@ def test_forced_rccl_on_a_shared_gpu_fails_loudly(tmp_path, monkeypatch):
     assert all("RCCL" in o and "one GPU per rank" in o for o in logs), logs
 
 
-def test_connect_without_finalize_keeps_the_windows(tmp_path):
-    """a launcher written for round 1 (export, all-gather, connect - no status / finalize round) still gets the window exchange"""
-    ranks = run_ranks(2, "c2f20_nofinalize", tmp_path, 29632)
-    assert all((res["counters"] == ranks[0]["counters"]).all() for res in ranks) and ranks[0]["counters"][1] == 35
+def test_connect_without_finalize_is_refused(tmp_path):
+    """sf3d_dist_connect alone does not connect a multi-rank model: the ranks' common decision comes with sf3d_dist_finalize (a rank
+    whose windows failed while the others' passed would otherwise leave the others spinning in the in-kernel exchange): the first
+    call that needs the exchange fails with a message on every rank"""
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), "2", "29632", "c2f20_nofinalize", str(tmp_path / f"r{r}.npz")],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode != 0 for p in procs), logs
+    assert all("sf3d_dist_finalize" in o for o in logs), logs

@@ -1,0 +1,75 @@
+"""BASELINE config 5 as specified - the Ravone PROJECT (DEM + soil map + soil database + land use through
+criteria3d_amd.project3d, pinned in tests/test_project3d.py) - on the HIP product against the oracle, into the runoff regime."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from criteria3d_amd import capi, catchment as cm
+from tests.scenarios import ravone_project_model
+
+pytestmark = pytest.mark.gpu
+COUNTERS = ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores")
+
+
+def _compare(product, oracle, m, what):
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    rel = np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9))
+    assert rel < 1e-6, (what, rel)
+    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6, what
+    for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
+        assert abs(g[k] - o[k]) <= 1e-6 * max(abs(o[k]), 1e-3), (what, k, g[k], o[k])
+    gc, oc = product.counters(), oracle.counters()
+    for k in COUNTERS:
+        assert gc[k] == oc[k], (what, k, gc, oc)
+    return rel
+
+
+def test_project_window_two_hours_match_oracle(product, oracle):
+    """128 x 128 window of the project (rows 72:200, cols 300:428: three soils, the one cell that has a land unit but no soil,
+    catchment edge with runoff outlets): 25 mm in hour 0 and a dry hour 1, both in full - a few thousand computeStep calls that end
+    at the minimum time step with restore-best steps.  H within 1e-6, every accepted dt and every work counter identical."""
+    m = ravone_project_model((72, 200, 300, 428))
+    assert m.ns > 12000 and m.n > 150000
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=64)
+    for h, mm in enumerate((25.0, 0.0)):
+        _, gd = cm.run_hour(product, m, mm)
+        _, od = cm.run_hour(oracle, m, mm)
+        assert len(gd) == len(od), (h, len(gd), len(od))
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+        _compare(product, oracle, m, f"hour {h}")
+    c = oracle.counters()
+    assert c["accepted"] > 1500 and c["restores"] > 0 and c["courant_rejections"] > 0, c
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+def test_project_full_size_runoff_regime_matches_oracle(product, oracle):
+    """The whole project (5.5 M nodes).  The product alone runs the 25 mm hour and the start of the dry hour (several hundred steps,
+    down to the minimum time step); its state - H of every node and the adaptive time step - is then handed to BOTH libraries
+    through the state setters (the application's own restart path, criteria3DProject.cpp:2934-3123), and both take the next 300
+    computeStep calls of the runoff regime from there: H within 1e-6, identical accepted dt, identical counters, restore-best
+    steps among them."""
+    m = ravone_project_model(None)
+    assert m.ns == 422282 and m.n > 5_000_000
+    product.check(product.lib.sf3d_reset_solver_state(), "reset")
+    cm.build(product, m)
+    cm.run_hour(product, m, 25.0)
+    cm.run_hour(product, m, 0.0, max_steps=400)
+    warm = product.counters()
+    H0, dt0 = product.total_potential(0, m.n), product.lib.sf3d_get_time_step()
+    assert np.all(np.isfinite(H0)) and warm["accepted"] > 600
+    dts = {}
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=64)
+        sf.set_total_potential_bulk(0, H0)
+        sf.check(sf.lib.sf3d_set_time_step(dt0), "set_time_step")
+        sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
+        _, dts[sf.backend] = cm.run_hour(sf, m, 0.0, max_steps=300)
+    np.testing.assert_allclose(dts[product.backend], dts[oracle.backend], rtol=1e-12)
+    _compare(product, oracle, m, "300 steps")
+    c = oracle.counters()
+    assert c["accepted"] == 300 and c["restores"] > 0, c
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
