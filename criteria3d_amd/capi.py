@@ -126,6 +126,7 @@ SIGNATURES = {
     "sf3d_get_nodes_temperature": (u8, [u32, u32, pd]),
     "sf3d_set_nodes_boundary_heat": (u8, [i32, u32, p32, pd]),
     "sf3d_get_counters": (u8, [p64]),
+    "sf3d_get_linear_residual": (f64, []),
     "sf3d_get_time_step": (f64, []),
     "sf3d_set_time_step": (u8, [f64]),
     "sf3d_reset_solver_state": (u8, []),

@@ -702,6 +702,7 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
     out[7] = 0;
     return SF3D_OK;
 }
+double sf3d_get_linear_residual(void) { return dev().ready() ? dev().ctrl().lastNorm : -9999.; }
 double sf3d_get_time_step(void) { return P.dtCurr; }
 sf3d_error_t sf3d_set_time_step(double dt)
 {

@@ -252,9 +252,7 @@ struct DevView {
     /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
-    /* the same chunks in the order the assembly walks them: [0, nListSurf) surface (k_assemble), [nListSurf, nAsmGen) soil chunks
-     * that need the general row code (k_assemble), [nAsmGen, nList) soil chunks with ChunkDesc::soilUniform (k_assemble_uniform) */
-    const uint32_t* asmList; uint32_t nAsmGen, nbAsmU;
+    const uint32_t* asmList;            /* = chunkList: the order the assembly walks the chunks in */
     const uint16_t* lmask;      /* bit s: the node has a link in (device) slot s */
     uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once
                                            per approximation (k_post) instead of once per sweep, off the critical path (SF3D_HALO_DIRECT=0: old way) */
@@ -302,6 +300,6 @@ struct DevView {
 };
 
 /* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */
-enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_COUNT };
+enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_APPROX_PATCH, KID_COUNT };
 
 #endif

@@ -712,8 +712,8 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_query(DevView v)
 
 /* ---- waterFlow = sink (+ evaporation clamp) + boundary flow (water.cpp:632-807) ---- */
 template <bool HEAT>
-__device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c, uint32_t i, double H, double Ho,
-                                                double z, double K, double Se)
+__device__ __forceinline__ double boundary_update(const DevView& v, const Ctrl* c, uint32_t i, double H, double Ho,
+                                                  double z, double K, double Se)
 {
     const double dt = c->dt;
     double flow = v.sink[i];
@@ -806,6 +806,7 @@ __device__ __forceinline__ void boundary_update(const DevView& v, const Ctrl* c,
     }
     if (bt != SF3D_BND_NONE) v.bflowRate[i] = rate;
     v.flow[i] = flow;
+    return flow;
 }
 
 
@@ -1059,43 +1060,10 @@ __device__ __forceinline__ double store_row(const DevView& v, sf3d_d2* __restric
     return bi;
 }
 
-/* The first Jacobi sweep of an approximation (JacobiWaterCPU, water.cpp:565-601) for the row that was just assembled:
- * its coefficients and right-hand side are still in registers, so the sweep's 112 B/node of matrix, b, z and x reads are
- * saved - the same statements in the same order as k_sweep, hence the same bits.  Returns the row's norm term. */
-template <bool NT>
-__device__ __forceinline__ double first_sweep_row(const DevView& v, const ChunkDesc& cd, uint32_t i, const double (&a)[SF3D_SLOTS],
-                                                  double bi, const double* __restrict__ xin, double* __restrict__ xout)
-{
-    uint32_t j[SF3D_SLOTS];
-    double xj[SF3D_SLOTS];
-    __builtin_amdgcn_sched_barrier(0);        /* the gathers below must not be hoisted into the assembly (registers) */
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) {
-        if (cd.kind[s] == CK_MIXED) j[s] = load_stream<NT>(&v.lto[(size_t)s * v.N + i]);
-        else j[s] = i + cd.delta[s];
-    }
-    const double zi = v.z[i], xi = xin[i];
-    #pragma unroll
-    for (int s = 0; s < SF3D_SLOTS; ++s) xj[s] = xin[j[s]];
-    double xn = bi;
-    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-    #pragma unroll
-    for (int o = 0; o < SF3D_SLOTS; ++o) {
-        const uint32_t s = order[o];
-        if (a[s] != 0.) xn -= a[s] * xj[s];
-    }
-    if (i < v.ns) xn = dmax(xn, zi);
-    double d = fabs(xn - xi);
-    const double psi = fabs(xn - zi);
-    if (psi > 1.) d *= (1. / psi);
-    xout[i] = xn;
-    return d;
-}
-
 /* rows of chunks [0, qSplit): every surface node (runoff + infiltration links) and, when
  * nrSurfaceNodes is not a multiple of 64, the first soil nodes; any link kind; Courant maximum */
-template <bool NT, bool HEAT, bool SWEEP0>
-__device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk, double* __restrict__ xout, double& nrm)
+template <bool NT, bool HEAT>
+__device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
     const double* __restrict__ Xc = v.X[c->cur];
@@ -1131,8 +1099,7 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
             k[s] = ks;
             sum += ks;
         }
-        const double bi = store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
-        if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
+        store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
     }
     return block_max(courant);
 }
@@ -1149,17 +1116,11 @@ __device__ __forceinline__ double assemble_surface_rows(const DevView& v, uint32
 #ifndef SF3D_ASM_WAVES
 #define SF3D_ASM_WAVES 4
 #endif
-#ifndef SF3D_ASM_DIST_FROM_DESC
-#define SF3D_ASM_DIST_FROM_DESC 0   /* 1: chunk-uniform link distances from the descriptor (scalar) instead of the 80 B/node ldist stream */
-#endif
-#ifndef SF3D_ASM_UNIFORM_PATH
-#define SF3D_ASM_UNIFORM_PATH 1   /* scalar-geometry path for chunks whose ChunkDesc::soilUniform is set */
-#endif
 #ifndef SF3D_ASM_GROUPS
 #define SF3D_ASM_GROUPS 2      /* 2 groups of 5 slots (5 groups of 2, 1 of 10: tuning experiments) */
 #endif
-template <bool NT, bool HEAT, bool SWEEP0>
-__device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk, double* __restrict__ xout, double& nrm)
+template <bool NT, bool HEAT>
+__device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t blk, uint32_t nblk)
 {
     const Ctrl* c = v.ctrl;
     const double* __restrict__ Xc = v.X[c->cur];
@@ -1169,17 +1130,12 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
     const uint32_t meanType = c->meanType;
     constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
     const uint32_t lane_ = threadIdx.x & 63u;
-    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nListSurf + blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nAsmGen;
+    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nListSurf + blk * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nList;
          li_ += nblk * (SF3D_BLOCK / 64)) {
         const uint32_t q = __builtin_amdgcn_readfirstlane(v.asmList[li_]);
         const uint32_t i = q * SF3D_CHUNK + lane_;
         if (NOT_MINE(v, i)) continue;
         const ChunkDesc cd = v.cdesc[q];                                    /* wave-uniform: scalar load */
-#if SF3D_ASM_DIST_FROM_DESC == 2
-        __shared__ double sdistAll[SF3D_BLOCK / 64][16];
-        double* sdist = sdistAll[threadIdx.x >> 6];
-        if (lane_ < SF3D_SLOTS) sdist[lane_] = v.cdesc[q].dist[lane_];
-#endif
         const double Hoi = Xh[i], Ki = v.K[i];
         const double Ci = v.C[i], flowi = v.flow[i];       /* for the row's diagonal and right-hand side: requested with the first loads, not after the last logarithm */
         double k[SF3D_SLOTS];
@@ -1202,15 +1158,7 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
                         j[t] = jj < v.N ? jj : i;
                     } else { kd[t] = load_stream<NT>(&v.lkind[e]); j[t] = load_stream<NT>(&v.lto[e]); }
                     area[t] = ((cd.areaUniform >> s) & 1u) ? cd.area[s] : load_stream<NT>(&v.larea[e]);
-#if SF3D_ASM_DIST_FROM_DESC == 2
-                    /* chunk-uniform distance: the descriptor's ten distances were staged in LDS by the wave (one 80-byte load per chunk);
-                     * every lane reads the same word - a broadcast, a few cycles, no scalar registers */
-                    if (!((cd.distUniform >> s) & 1u)) dist[t] = load_stream<NT>(&v.ldist[e]);      /* else: sdist[s], read where it is used */
-#elif SF3D_ASM_DIST_FROM_DESC
-                    dist[t] = ((cd.distUniform >> s) & 1u) ? cd.dist[s] : load_stream<NT>(&v.ldist[e]);
-#else
                     dist[t] = load_stream<NT>(&v.ldist[e]);
-#endif
                 }
             }
             #pragma unroll
@@ -1219,11 +1167,7 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
             for (int t = 0; t < GS; ++t) {
                 const uint32_t s = order[g * GS + t];
                 double ks = 0.;
-#if SF3D_ASM_DIST_FROM_DESC == 2
-                const double dd = ((cd.distUniform >> s) & 1u) ? sdist[s] : dist[t];
-#else
                 const double dd = dist[t];
-#endif
                 if (kd[t] == LK_SOIL_LAT) {                                  /* redistribution, water.cpp:542-562 */
                     const double ki = Ki * lvRatio, kn = kj[t] * lvRatio;
                     ks = qdiv(mean_of(ki, kn, meanType) * area[t], dd);
@@ -1244,106 +1188,38 @@ __device__ __forceinline__ void assemble_soil_rows(const DevView& v, uint32_t bl
 #endif
             }
         }
-        const double bi = store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
-        if (SWEEP0) nrm += first_sweep_row<NT>(v, cd, i, k, bi, Xc, xout);
-    }
-}
-
-/* Soil rows of the chunks whose link geometry is the chunk's (ChunkDesc::soilUniform: interior of a regular grid below layer 1,
- * 75 % of the chunks of a 512-wide grid): link kind, neighbour offset, interface area and link distance of every slot sit in
- * scalar registers, the only per-lane loads are Hold, K, C, waterFlow and the ten neighbour conductivities - all in flight before
- * the first logarithm - and the row needs so few vector registers that more waves per SIMD hide the divide -> log -> divide
- * chains of each other.  Same statements in the same order as assemble_soil_rows, hence the same bits.  Launched BEFORE
- * k_assemble (whose last block takes the Courant decision and moves the stage on). */
-#ifndef SF3D_ASMU_WAVES
-#define SF3D_ASMU_WAVES 5
-#endif
-template <bool NT>
-__global__ void __launch_bounds__(SF3D_BLOCK, SF3D_ASMU_WAVES) k_assemble_uniform(DevView v)
-{
-    const Ctrl* c = v.ctrl;
-    if (c->stage != ST_APPROX) return;
-    fm_init();
-    const double* __restrict__ Xh = v.X[c->hold];
-    const double dt = c->dt, lvRatio = c->lvRatio;
-    sf3d_d2* __restrict__ A2w = cur_A2(v);
-    const uint32_t meanType = c->meanType;
-    constexpr uint32_t order[SF3D_SLOTS] = {0, 2, 3, 4, 5, 6, 7, 8, 9, 1};
-    const uint32_t lane_ = threadIdx.x & 63u;
-    for (uint32_t li_ = __builtin_amdgcn_readfirstlane(v.nAsmGen + blockIdx.x * (SF3D_BLOCK / 64) + (threadIdx.x >> 6)); li_ < v.nList;
-         li_ += gridDim.x * (SF3D_BLOCK / 64)) {
-        const uint32_t q = __builtin_amdgcn_readfirstlane(v.asmList[li_]);
-        const uint32_t i = q * SF3D_CHUNK + lane_;
-        if (NOT_MINE(v, i)) continue;
-        const ChunkDesc& cd = v.cdesc[q];                               /* wave-uniform address: scalar loads, field by field */
-        const double Hoi = Xh[i], Ki = v.K[i], Ci = v.C[i], flowi = v.flow[i];
-        const uint32_t has = (cd.soilUniform == 2) ? (uint32_t)v.lmask[i] : 0x3FFu;      /* row ends: which of the chunk's links this node has */
-        double kj[SF3D_SLOTS], k[SF3D_SLOTS];
-        #pragma unroll
-        for (int s = 0; s < SF3D_SLOTS; ++s) kj[s] = (cd.ukind[s] != CK_NONE && ((has >> s) & 1u)) ? v.K[i + cd.delta[s]] : 0.;
-        double sum = 0.;
-        #pragma unroll
-        for (int o = 0; o < SF3D_SLOTS; ++o) {
-            const uint32_t s = order[o];
-            double ks = 0.;
-            if (cd.ukind[s] == LK_SOIL_LAT) {                            /* redistribution, water.cpp:542-562 */
-                const double ki = Ki * lvRatio, kn = kj[s] * lvRatio;
-                if ((has >> s) & 1u) ks = qdiv(mean_of(ki, kn, meanType) * cd.area[s], cd.dist[s]);
-            } else if (cd.ukind[s] == LK_SOIL_VERT) {
-                if ((has >> s) & 1u) ks = qdiv(mean_of(Ki, kj[s], meanType) * cd.area[s], cd.dist[s]);
-            }
-            k[s] = ks;
-            sum += ks;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, 0., Ci, flowi);
+        store_row<NT>(v, A2w, cd, i, k, sum, Hoi, dt, invFlux, Ci, flowi);
     }
 }
 
 /* one launch: blocks [0, nbSurf) assemble the surface rows (and reduce the Courant maximum),
  * blocks [nbSurf, nbSurf + nbSoil) the soil rows.  FUSED: the block that arrives last takes the
  * Courant decision (checkCourant) instead of a separate one-block kernel. */
-/* SWEEP0 (one GPU, fused decisions, SF3D_FUSE_FIRST_SWEEP=1): every row is also swept once while it is in registers
- * (first_sweep_row) and the last block, after a passed Courant check, takes the convergence decision of that first iteration -
- * one k_sweep launch less per approximation.  After a failed Courant check the swept values sit in a free buffer and are
- * never looked at.  Same results, but off by default: at 4 waves/SIMD the eleven extra gathers cost k_assemble 186 us, more
- * than the 126 us sweep they replace. */
-template <bool FUSED, bool NT, bool HEAT, bool SWEEP0, bool ALLROWS>
+template <bool FUSED, bool NT, bool HEAT>
 __device__ __forceinline__ void body_assemble(const DevView& v)
 {
     fm_init();
-    const int nxt = free_buffer(v.ctrl);                  /* where k_sweep would write its first iterate */
-    double* __restrict__ xout = v.X[nxt];
-    double bm = 0., nrm = 0.;
-    if (ALLROWS) {          /* persistent step kernel: every block takes its share of the surface rows, then of the soil rows */
-        bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, gridDim.x, xout, nrm);
-        assemble_soil_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, gridDim.x, xout, nrm);
-    }
-    else if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT, SWEEP0>(v, blockIdx.x, v.nbSurf, xout, nrm);
-    else assemble_soil_rows<NT, HEAT, SWEEP0>(v, blockIdx.x - v.nbSurf, v.nbSoil, xout, nrm);
+    double bm = 0.;
+    if (blockIdx.x < v.nbSurf) bm = assemble_surface_rows<NT, HEAT>(v, blockIdx.x, v.nbSurf);
+    else assemble_soil_rows<NT, HEAT>(v, blockIdx.x - v.nbSurf, v.nbSoil);
     if (!FUSED) {
-        if (threadIdx.x == 0 && (ALLROWS || blockIdx.x < v.nbSurf)) v.part0[blockIdx.x] = bm;
+        if (threadIdx.x == 0 && blockIdx.x < v.nbSurf) v.part0[blockIdx.x] = bm;
         return;
     }
-    const double bs = SWEEP0 ? block_sum(nrm) : 0.;
     __syncthreads();
-    if (!arrive_last(v, bm, bs, SWEEP0)) return;
+    if (!arrive_last(v, bm, 0., false)) return;
     double m = 0.;                                        /* soil blocks published 0: the maximum is unchanged */
     for (uint32_t k = threadIdx.x; k < gridDim.x; k += SF3D_BLOCK)
         m = dmax(m, __hip_atomic_load(&v.part0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     double vals[3] = {block_max(m), 0., 0.};
-    const double norm = SWEEP0 ? sum_published(v.part1, gridDim.x) : 0.;
     if (!dist_allgather(v, v.ctrl, vals, 1)) return;
-    if (threadIdx.x == 0) {
-        courant_decision(v.ctrl, vals[0]);
-        if (SWEEP0 && v.ctrl->stage == ST_SWEEP) sweep_decision(v.ctrl, nxt, norm / v.N);
-    }
+    if (threadIdx.x == 0) courant_decision(v.ctrl, vals[0]);
 }
-template <bool FUSED, bool NT, bool HEAT, bool SWEEP0 = false>
+template <bool FUSED, bool NT, bool HEAT>
 __global__ void __launch_bounds__(SF3D_BLOCK, HEAT ? SF3D_ASM_HEAT_WAVES : SF3D_ASM_WAVES) k_assemble(DevView v)
 {
     if (v.ctrl->stage != ST_APPROX) return;
-    body_assemble<FUSED, NT, HEAT, SWEEP0, false>(v);
+    body_assemble<FUSED, NT, HEAT>(v);
 }
 
 #include "sf3d_cg.inc"          /* k_cg_*: preconditioned conjugate gradients standing in for the linealia hook */
@@ -1517,6 +1393,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 }
 
 #include "sf3d_pair.inc"        /* k_sweep_pair: two Jacobi iterations per pass through an LDS ring */
+#include "sf3d_patch.inc"       /* k_approx_patch: node properties + soil rows of an approximation in one layer-marching pass */
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
                                               double Se, double& st, double& sk)
@@ -1669,7 +1546,6 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_accept(DevView v)
     body_accept<NT>(v);
 }
 
-#include "sf3d_persistent.inc"  /* k_step_persistent: one launch per computeStep (measured alternative) */
 
 /* The two halves of k_accept for the overlapped mode: the boundary sums stay in the step (the next step's k_props
  * overwrites bflowRate); the link sums - 1.5 GB of traffic at C4, 6 % VALU - run on a second stream next to the next
@@ -1740,7 +1616,7 @@ template <class F> void parallel_for(uint32_t n, F f)
     for (auto& t : th) t.join();
 }
 
-const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept", "k_sweep_pair"};
+const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept", "k_sweep_pair", "k_approx_patch"};
 
 }  // namespace
 
@@ -1804,7 +1680,6 @@ __global__ void k_dist_ping(DistView d, unsigned long long token, long long time
 struct DeviceSolver::Impl {
     int device = -1;
     hipStream_t stream = nullptr;
-    hipStream_t stream3 = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;   /* SF3D_ASM_UNIFORM=2: chunk-uniform soil rows next to the general ones */
     hipStream_t stream2 = nullptr;         /* link flow sums of the accepted step, next to the next step's k_props */
     hipEvent_t evLinks[2] = {nullptr, nullptr};   /* one per copy of the matrix: recorded after the link sums that read it */
     bool linksPending[2] = {false, false};
@@ -1881,11 +1756,9 @@ struct DeviceSolver::Impl {
     /* timing */
     int timing = 0;                       /* 0 off, 1 every node kernel, 2 only k_sweep, on every 8th step */
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
-    int fuseFirstSweep = -1;              /* SF3D_FUSE_FIRST_SWEEP=1: k_assemble also does the first Jacobi iteration (measured slower) */
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
-    int persistent = -1;                   /* -1 not decided yet for this model, 0 off, 1: one launch per computeStep (k_step_persistent) */
-    uint32_t persistBlocks = 0;
     uint32_t pairBlocks = 0;              /* grid of k_sweep_pair (0: the graph is no regular grid, or the paired sweep is off) */
+    uint32_t patchBlocks = 0, patchW = 0; /* grid and patch height of k_approx_patch (0: off) */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -1941,8 +1814,7 @@ sf3d_error_t DeviceSolver::release()
     built_ = false;
     fatal_ = false;
     /* the SF3D_* mode switches are read again when the next model is built (tests toggle them between models of one process) */
-    I.overlapAccept = I.useFused = I.useGraphs = I.fuseFirstSweep = I.residentGrids = -1;
-    I.persistent = -1; I.persistBlocks = 0;
+    I.overlapAccept = I.useFused = I.useGraphs = I.residentGrids = -1;
     return SF3D_OK;
 }
 
@@ -2268,53 +2140,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             std::stable_partition(listSoil.begin(), listSoil.end(), first);
         }
         listSurf.insert(listSurf.end(), listSoil.begin(), listSoil.end());
-        {   /* XCD banding.  Workgroup b runs on XCD b % 8 (round-robin dispatch) and walks the list in groups of four
-             * chunks, so list group g is processed by XCD g % 8: consecutive groups land on different XCDs and every XCD's
-             * L2 fetches the x values of the rows above and below its own.  Within each block of P chunks - P = the
-             * vertical period of the numbering (one layer of a layer-major grid) - the groups are transposed (P/32 x 8) so
-             * that XCD k gets the contiguous band k of every layer: lateral and vertical neighbours then sit in the same
-             * L2.  Any order of the list is valid; this one only applies when the numbering has such a period. */
-            const char* e = getenv("SF3D_XCD_BANDS");
-            const bool want = e ? (e[0] != '0') : false;
-            uint32_t P = 0;
-            if (want && nChunks > 0) {
-                std::vector<int64_t> deltas;
-                for (uint32_t q = v.qSplit; q < nChunks; q += (nChunks / 64 + 1)) if (cdesc[q].kind[1] == LK_SOIL_VERT) deltas.push_back(cdesc[q].delta[1]);
-                if (!deltas.empty()) {
-                    std::sort(deltas.begin(), deltas.end());
-                    const int64_t d = deltas[deltas.size() / 2];
-                    if (d > 0 && d % (SF3D_CHUNK * 32) == 0) P = (uint32_t)(d / SF3D_CHUNK);
-                }
-            }
-            if (P >= 256 && v.nListSurf % 32 == 0) {
-                const uint32_t per = SF3D_BLOCK / SF3D_CHUNK, groupsPerLayer = P / per, band = groupsPerLayer / 8;
-                std::vector<uint32_t> src(listSurf);
-                for (size_t base = 0; base + P <= src.size(); base += P)
-                    for (uint32_t k = 0; k < 8; ++k)
-                        for (uint32_t r = 0; r < band; ++r)
-                            for (uint32_t w = 0; w < per; ++w)
-                                listSurf[base + (size_t)(8 * r + k) * per + w] = src[base + (size_t)(band * k + r) * per + w];
-            }
-        }
-
-        std::vector<uint32_t> asmOrder(listSurf);                   /* listSurf now holds the whole list */
-        {
-            const char* ue = getenv("SF3D_ASM_UNIFORM");
-            const char* fe = getenv("SF3D_FUSE_FIRST_SWEEP");
-            /* the heat variant of the rows (thermal fluxes) and the fused first sweep live in k_assemble only */
-            /* OFF by default (SF3D_ASM_UNIFORM=1 turns it on): measured at C4, 166 us for the 71 % uniform chunks + 233 us for the rest, one
-             * after the other, against 300 us for everything in one launch - alone, the general rows (row ends, layer 1, surface) are
-             * latency-bound at 4 waves/SIMD; inside the single kernel their waiting is hidden by the other rows' arithmetic */
-            const bool want = !m.heat && (ue && (ue[0] == '1' || ue[0] == '2')) && !(fe && fe[0] == '1');
-            auto soilBegin = asmOrder.begin() + v.nListSurf;
-            auto mid = asmOrder.end();
-            if (want) mid = std::stable_partition(soilBegin, asmOrder.end(), [&](uint32_t q) { return cdesc[q].soilUniform == 0; });
-            v.nAsmGen = (uint32_t)(mid - asmOrder.begin());
+        {   /* grids of the two halves of k_assemble */
             const uint32_t per = SF3D_BLOCK / SF3D_CHUNK;
             auto blocks = [&](uint32_t chunks) { uint32_t b = (chunks + per - 1) / per; if (b > SF3D_MAX_BLOCKS) b = SF3D_MAX_BLOCKS; return b; };
-            v.nbSoil = blocks(v.nAsmGen - v.nListSurf);
+            v.nbSoil = blocks(v.nList - v.nListSurf);
             if (const char* be = getenv("SF3D_ASM_SOIL_BLOCKS")) { const uint32_t nb = (uint32_t)atoi(be); if (nb > 0 && nb < v.nbSoil) v.nbSoil = nb; }   /* tuning */
-            v.nbAsmU = blocks(v.nList - v.nAsmGen);
         }
         double *z, *size, *pond, *sink, *bslope, *bsize, *prescribed, *roughness, *larea, *ldist;
         uint16_t* cls; uint8_t *btype, *lkind; uint32_t* lto; SoilDev* soils; ChunkDesc* dcdesc;
@@ -2333,9 +2163,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         uint32_t* dlist; HIP_TRY(dev_alloc(I.allocs, dlist, listSurf.size()));
         if (!listSurf.empty()) HIP_TRY(hipMemcpy(dlist, listSurf.data(), listSurf.size() * 4, hipMemcpyHostToDevice));
         v.chunkList = dlist;
-        {   uint32_t* dasm; HIP_TRY(dev_alloc(I.allocs, dasm, asmOrder.size()));
-            if (!asmOrder.empty()) HIP_TRY(hipMemcpy(dasm, asmOrder.data(), asmOrder.size() * 4, hipMemcpyHostToDevice));
-            v.asmList = dasm; }
+        v.asmList = dlist;              /* the assembly walks the chunks in list order */
         v.owner = nullptr; v.dist = nullptr;
         {   /* bytes one rank touches per sweep: 152 B per owned node.  Below the 256 MiB Infinity Cache the whole
              * sweep working set stays cached between sweeps and bypassing costs ~8 % (measured at 0.98 M nodes);
@@ -2344,12 +2172,30 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             const double sweepBytes = 152.0 * (double)v.nList * SF3D_CHUNK;
             v.ntStream = e ? (e[0] != '0') : (sweepBytes > 256.0 * 1024 * 1024);
         }
-        I.pairBlocks = 0;
+        I.pairBlocks = 0; I.patchBlocks = 0; I.patchW = 0;
         if (!pairNode.empty()) {
             /* the paired sweep pays where the sweep streams from HBM (ntStream: above the Infinity Cache) - below that the plain sweep
              * is cache-resident and faster; SF3D_PAIR_SWEEP=1 forces it on any regular grid (tests on small grids) */
             const char* pe = getenv("SF3D_PAIR_SWEEP");
             const bool on = pe ? (pe[0] != '0') : (v.ntStream != 0);
+            /* the layer-marching approximation kernel (k_approx_patch) shares the grid description: on wherever the paired sweep is,
+             * SF3D_APPROX_PATCH=0/1 forces; water only (the heat variant of the rows lives in k_assemble) */
+            const char* ae = getenv("SF3D_APPROX_PATCH");
+            const bool patchOn = !m.heat && (ae ? (ae[0] != '0') : (v.ntStream != 0));
+            if (patchOn) {
+                uint32_t W = 10; if (const char* we = getenv("SF3D_PATCH_W")) W = (uint32_t)atoi(we);
+                if (W != 6 && W != 10 && W != 14) W = 10;
+                while (W > 6 && pairNY < W) W -= 4;
+                if (pairNY >= W) { I.patchW = W; I.patchBlocks = (pairNX / 64) * ((pairNY + W - 3) / (W - 2)); }
+            }
+            if (I.patchBlocks && !on) {          /* the grid description alone (no paired sweep) */
+                uint64_t *dn, *dq;
+                HIP_TRY(dev_alloc(I.allocs, dn, pairNode.size())); HIP_TRY(dev_alloc(I.allocs, dq, pairChunk.size()));
+                HIP_TRY(hipMemcpy(dn, pairNode.data(), pairNode.size() * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(dq, pairChunk.data(), pairChunk.size() * 8, hipMemcpyHostToDevice));
+                v.pair.NX = pairNX; v.pair.NY = pairNY; v.pair.NZ = pairNZ; v.pair.W = 0; v.pair.patchCols = pairNX / 64; v.pair.patchRows = 0;
+                v.pair.nodeCode = dn; v.pair.chunkCode = dq;
+            }
             if (on) {
                 int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, I.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
                 uint32_t bestW = 0; double bestCost = 1e30;
@@ -2467,7 +2313,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
-        {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, I.pairBlocks) + 8;
+        {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, std::max(I.pairBlocks, I.patchBlocks)) + 8;
             HIP_TRY(dev_alloc(I.allocs, v.part0, np)); HIP_TRY(dev_alloc(I.allocs, v.part1, np)); }
         HIP_TRY(dev_alloc(I.allocs, v.arrive, 16 * 17)); HIP_TRY(hipMemset(v.arrive, 0, 16 * 17 * sizeof(unsigned int)));
         HIP_TRY(dev_alloc(I.allocs, v.gridBar, 16)); HIP_TRY(hipMemset(v.gridBar, 0, 16 * sizeof(unsigned int)));
@@ -3045,9 +2891,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool heatOn = v.heat.on != 0;
     if (I.useFused < 0) { const char* e = getenv("SF3D_FUSED_DECIDE"); I.useFused = (e && e[0] == '0') ? 0 : 1; }
     if (I.residentGrids < 0) { const char* e = getenv("SF3D_RESIDENT_GRIDS"); I.residentGrids = (e && e[0] == '0') ? 0 : 1; }
-    if (I.fuseFirstSweep < 0) { const char* e = getenv("SF3D_FUSE_FIRST_SWEEP"); I.fuseFirstSweep = (e && e[0] == '1') ? 1 : 0; }   /* measured slower: off */
     const bool compat = v.compatCv != nullptr;   /* quirk-1 emulation: rows are stored raw and normalised by k_compat_rows after the Courant decision */
-    const bool fuse0 = I.useFused && I.fuseFirstSweep && !multi && !heatOn && !compat && v.nAsmGen == v.nList && !(p.lineal && v.cgDiag != nullptr);      /* k_assemble also does the first Jacobi iteration */
     /* grids of the register-heavy kernels: exactly as many blocks as are resident at once - equal work per block, no tail
      * round (at 70 VGPRs only 1 792 of 2 048 blocks fit and the remaining 256 ran alone afterwards).  Every kernel walks the
      * chunk list with its own gridDim, and the fused reductions count gridDim partials, so any grid is valid. */
@@ -3069,9 +2913,12 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool fused = !multi && I.useFused;   /* sweep + convergence decision in one launch (single GPU) */
     const bool fusedMulti = multi && I.useFused; /* + in-kernel halo puts and all-gather (multi GPU) */
     const bool linealOn = p.lineal && v.cgDiag != nullptr && !multi && I.useFused;     /* the linealia stand-in: device conjugate gradients */
-    const bool pairOn = fused && I.pairBlocks != 0 && !fuse0 && !linealOn;   /* k_sweep_pair instead of k_sweep */
+    const bool pairOn = fused && I.pairBlocks != 0 && !linealOn;   /* k_sweep_pair instead of k_sweep */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
+    /* node properties + soil rows of an approximation in one layer-marching launch (k_approx_patch), surface rows + Courant decision
+     * by k_assemble's surface blocks right after it */
+    const bool patchOn = fused && I.patchBlocks != 0 && !heatOn;
 
     /* mode 2 samples: the sweeps of every 8th computeStep carry HIP events (eager launches); the other
      * steps replay hipGraphs, so the measurement costs ~1 % instead of ~6 % */
@@ -3099,46 +2946,15 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     }
     uint32_t stage = ST_ACCEPT;
     if (m.water) {
-    if (I.persistent < 0) {
-        /* one launch per computeStep for small grids (kernel boundaries cost more than the kernels there): one GPU, water only, plain
-         * sweeps; automatic below SF3D_PERSISTENT_MAX_NODES (default 1.5 M nodes), SF3D_PERSISTENT=0/1 forces */
-        const char* pe = getenv("SF3D_PERSISTENT");
-        double maxNodes = 1.5e6; if (const char* me = getenv("SF3D_PERSISTENT_MAX_NODES")) maxNodes = atof(me);
-        bool on = !multi && !heatOn && !compat && I.useFused && I.pairBlocks == 0 && v.nAsmGen == v.nList && !fuse0;
-        /* OFF unless SF3D_PERSISTENT=1: measured on MI355X the grid barrier (agent-scope release: L2 write-back, arrival, spin, acquire:
-         * invalidate - by every block) costs MORE than a kernel boundary of a graph replay: C2 F60 0.384 ms/step against 0.263,
-         * C3 F60 1.69 against 0.81 */
-        on = on && pe && pe[0] == '1' && (double)v.N <= maxNodes * 1e3;
-        I.persistent = 0;
-        if (on) {
-            int perCu = 0, dev = 0; hipDeviceProp_t prop;
-            const void* fn = v.ntStream ? (const void*)k_step_persistent<true> : (const void*)k_step_persistent<false>;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fn, SF3D_BLOCK, 0) == hipSuccess && perCu > 0 && hipGetDevice(&dev) == hipSuccess
-                && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
-                const uint32_t res = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;      /* all blocks must be resident at once */
-                I.persistBlocks = v.nb < res ? v.nb : res;
-                I.persistent = 1;
-            }
-        }
-    }
-    const bool persistentStep = I.persistent == 1 && !timedStep && I.timing != 1 && !linealOn;
     {   /* this step assembles into the copy of the matrix that the step before the last one used (k_step_begin flips Ctrl::aBuf): the
          * link flow sums that read it - queued two steps ago on the second stream - must be done; so must they before this step's
          * sweeps reuse the head buffer they read.  The sums of the LAST step run next to this whole step - unless this step adds its
-         * own sums inside the step (event-timed steps, the persistent kernel): then both must be done first. */
+         * own sums inside the step (event-timed steps): then both must be done first. */
         const uint32_t wb = (mirror_.aBuf ^ 1u) & 1u;
         if (I.linksPending[wb]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb], 0)); I.linksPending[wb] = false; }
-        if ((!overlap || persistentStep) && I.linksPending[wb ^ 1u]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb ^ 1u], 0)); I.linksPending[wb ^ 1u] = false; }
+        if (!overlap && I.linksPending[wb ^ 1u]) { HIP_TRY(hipStreamWaitEvent(st, I.evLinks[wb ^ 1u], 0)); I.linksPending[wb ^ 1u] = false; }
     }
-    if (persistentStep) {
-        if (v.ntStream) hipLaunchKernelGGL(k_step_persistent<true>, dim3(I.persistBlocks), block, 0, st, v, maxTimeStep);
-        else hipLaunchKernelGGL(k_step_persistent<false>, dim3(I.persistBlocks), block, 0, st, v, maxTimeStep);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(I.hostCtrl, v.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        stage = I.hostCtrl->stage;
-        if (I.hostCtrl->barTimeout) { snprintf(err_, sizeof(err_), "persistent step kernel: a grid barrier timed out (blocks not resident together? another process on the GPU?): set SF3D_PERSISTENT=0"); fatal_ = true; }
-    } else {
+    {
     hipLaunchKernelGGL(k_step_begin, one, one, 0, st, v.ctrl, maxTimeStep);
     stage = ST_APPROX;                      /* k_step_begin opens the first attempt */
     uint64_t before[8], atStart[8];
@@ -3165,45 +2981,31 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
                 hipLaunchKernelGGL(k_sync_kf, one, block, 0, st, v);
             }
     };
-    /* the soil rows with chunk-uniform link geometry: their own low-register kernel, queued before k_assemble (which decides) */
-    const dim3 asmUGrid = [&] { const dim3 r = v.ntStream ? resident((const void*)k_assemble_uniform<true>) : resident((const void*)k_assemble_uniform<false>);
-                                return dim3(v.nbAsmU < r.x ? (v.nbAsmU ? v.nbAsmU : 1u) : r.x); }();
-    /* SF3D_ASM_UNIFORM=2: the two assembly kernels side by side on two streams instead of one after the other */
-    static const bool wantConcurrent = getenv("SF3D_ASM_UNIFORM") && getenv("SF3D_ASM_UNIFORM")[0] == '2';
-    const bool concurrentRows = wantConcurrent && v.nAsmGen < v.nList && !multi && !heatOn && I.useFused && !fuse0;
-    if (concurrentRows && !I.stream3) {
-        HIP_TRY(hipStreamCreateWithFlags(&I.stream3, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&I.evFork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&I.evJoin, hipEventDisableTiming));
-    }
     static const bool asmNtOff = getenv("SF3D_ASM_NT") && getenv("SF3D_ASM_NT")[0] == '0';      /* tuning: cacheable stores of the rows */
     const bool asmNT = v.ntStream && !asmNtOff;
-    auto launch_uniform_rows = [&] {
-        if (v.nAsmGen >= v.nList) return;
-        if (asmNT) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, st, v);
-        else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, st, v);
-    };
     auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) {
+        if (withHead && patchOn) {
+            const dim3 agr(I.patchBlocks), abl((I.patchW + 1) * 64);
+            timed(KID_APPROX_PATCH, [&] {
+                switch (I.patchW * 2 + (asmNT ? 1 : 0)) {
+                    case 12: hipLaunchKernelGGL((k_approx_patch<6, false>), agr, abl, 0, st, v); break;
+                    case 13: hipLaunchKernelGGL((k_approx_patch<6, true>), agr, abl, 0, st, v); break;
+                    case 20: hipLaunchKernelGGL((k_approx_patch<10, false>), agr, abl, 0, st, v); break;
+                    case 21: hipLaunchKernelGGL((k_approx_patch<10, true>), agr, abl, 0, st, v); break;
+                    case 28: hipLaunchKernelGGL((k_approx_patch<14, false>), agr, abl, 0, st, v); break;
+                    default: hipLaunchKernelGGL((k_approx_patch<14, true>), agr, abl, 0, st, v); break;
+                }
+            });
+            /* the surface rows (runoff + infiltration from above) and the Courant decision: k_assemble's surface blocks alone */
+            timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf), block, 0, st, v); });
+        } else
         if (withHead) {
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else if (heatOn) { timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); }); hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v); }
-            else if (fuse0) timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
-            else if (concurrentRows) timed(KID_ASSEMBLE, [&] {
-                /* the chunk-uniform soil rows on a stream of their own NEXT TO the general rows (fork after k_props, join before the Courant
-                 * decision, which therefore is a kernel of its own here: the stage must not move while either kernel is running) */
-                hipEventRecord(I.evFork, st);
-                hipStreamWaitEvent(I.stream3, I.evFork, 0);
-                if (asmNT) hipLaunchKernelGGL(k_assemble_uniform<true>, asmUGrid, block, 0, I.stream3, v);
-                else hipLaunchKernelGGL(k_assemble_uniform<false>, asmUGrid, block, 0, I.stream3, v);
-                hipEventRecord(I.evJoin, I.stream3);
-                if (asmNT) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
-                else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v);
-                hipStreamWaitEvent(st, I.evJoin, 0);
-                hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
-            });
-            else if (I.useFused) timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+            else if (I.useFused) timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
             else {
-                timed(KID_ASSEMBLE, [&] { launch_uniform_rows(); if (asmNT) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
+                timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<false, true, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<false, false, false>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
                 if (I.rcclMode) { hipLaunchKernelGGL(k_local_reduce, one, block, 0, st, v, 1); I.rccl_gather(st); }
                 hipLaunchKernelGGL(k_decide_courant, one, block, 0, st, v);
             }
@@ -3276,14 +3078,14 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
      * batch queued simply continue an unfinished approximation); without a record, the last count plus two */
     auto predicted_sweeps = [&](uint32_t index, bool withHead) -> uint32_t {
         uint32_t chunk;
-        if (withHead && index < I.predCount && index < 16u) { chunk = I.pred[index] + 1; if (fuse0 && chunk > 1) --chunk; if (chunk < 2) chunk = 2; }
-        else { chunk = I.lastSweeps + (fuse0 ? 1 : 2); if (chunk < 4) chunk = 4; }      /* fuse0: the first iteration is done by k_assemble */
+        if (withHead && index < I.predCount && index < 16u) { chunk = I.pred[index] + 1; if (chunk < 2) chunk = 2; }
+        else { chunk = I.lastSweeps + 2; if (chunk < 4) chunk = 4; }
         if (chunk > 40) chunk = 40;
         return chunk;
     };
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
         if (!I.useGraphs || timedStep || I.rcclMode) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }   /* (RCCL calls are queued eagerly) */
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u) | (concurrentRows ? 1u << 24 : 0u);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u) | (patchOn ? 1u << 25 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -3316,10 +3118,9 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             /* attribute event pairs only to launches that really ran: how many of each kernel ran
              * comes from the device counters; guarded no-op launches are the shortest of a group */
             uint64_t ran[KID_COUNT];
-            ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
+            ran[KID_PROPS] = ran[KID_ASSEMBLE] = ran[KID_APPROX_PATCH] = c.counters[2] - before[2];
             ran[KID_SWEEP] = pairOn ? c.singleLaunches - singleBefore : c.counters[3] - before[3];
             ran[KID_SWEEP_PAIR] = c.pairLaunches - pairBefore;
-            if (fuse0) ran[KID_SWEEP] -= (c.counters[2] - before[2]) - (c.counters[4] - before[4]);   /* first iterations: inside k_assemble */
             ran[KID_POST] = c.counters[7] - before[7];
             ran[KID_RESTORE] = c.counters[6] - before[6];
             ran[KID_ACCEPT] = c.counters[1] - before[1];
@@ -3349,8 +3150,8 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
         I.predCount = I.hostCtrl->seqCount < 16u ? I.hostCtrl->seqCount : 16u;
         for (uint32_t k = 0; k < I.predCount; ++k) I.pred[k] = I.hostCtrl->seqSweeps[k];
     }
-    }   /* !persistentStep */
-    if (overlap && !persistentStep && stage == ST_ACCEPT) {
+    }
+    if (overlap && stage == ST_ACCEPT) {
         /* the main stream is drained (the poll just read the control block): no dependency to express for the launch */
         uint32_t lcap = 384u; if (const char* le = getenv("SF3D_LINKS_BLOCKS")) lcap = (uint32_t)atoi(le);      /* measured at C4: 2048 -1 %, 512 / 256 +1 %, 128 -4 % */
         const dim3 lgrid(v.nb > lcap ? lcap : v.nb);        /* a streaming kernel: few enough waves that k_props fits next to it */

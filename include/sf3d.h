@@ -312,6 +312,10 @@ sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint3
  * sources) and returns SF3D_MISSING_DATA_ERROR. */
 sf3d_error_t sf3d_get_counters(uint64_t out[8]);
 
+/* Stopping quantity of the LAST linear solve of the water system: Jacobi - the mean scaled update of the last sweep
+ * (JacobiWaterCPU's norm, water.cpp:592-600); conjugate gradients (the linealia stand-in) - the relative residual
+ * ||r~|| / ||b~|| of the normalised system.  -9999 where it is not tracked (the unmodified reference). */
+double sf3d_get_linear_residual(void);
 /* current adaptive time step deltaTcurr [s] (Solver::getTimeStep, solver.h:36) */
 double sf3d_get_time_step(void);
 /* Restore the adaptive time step of a checkpointed run (the reference keeps deltaTcurr only in

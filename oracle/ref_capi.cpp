@@ -164,6 +164,7 @@ sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint3
 sf3d_error_t sf3d_get_counters(uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 /* Solver::getTimeStep is public on the reference's global `solver` object but that object is
  * not part of the public header; not available here */
+double sf3d_get_linear_residual(void) { return -9999.; }   /* not tracked by the unmodified reference */
 double sf3d_get_time_step(void) { return SF3D_VAL_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_set_time_step(double) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_reset_solver_state(void) { return SF3D_MISSING_DATA_ERROR; }

@@ -22,7 +22,20 @@ def test_committed_bench_line_has_every_contract_field():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.5 < r.get("pass_frac", r["frac"]) < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if Path(files[-1]).name >= "r03":
+        # round 3 on: `frac` is a PHYSICAL fraction - the bytes one launch has to move over its duration - never above 1; the
+        # two-sweeps-per-launch pricing of the paired sweep lives in `equivalent_sweep_frac`; the whole timed region and the C4 F60
+        # hour 0 (runoff regime) are on the same line
+        assert 0.3 < r["frac"] <= 1.0, r["frac"]
+        assert r["kernel"] != "k_sweep_pair" or (r["equivalent_sweep_frac"] > r["frac"] and r["algorithmic_bytes_per_launch"] == 160 * 5242880)
+        st = r["step"]
+        assert 0.2 < st["frac"] <= 1.0 and st["bytes"] > 0 and st["elapsed_s"] > 0 and st["survey_8d_frac"] >= st["frac"]
+        f = line["f60_hour0"]
+        assert f["unit"] == "sim-h/s" and f["value"] > 0 and f["work"]["accepted"] == 76 and f["work"]["courant_rejections"] == 43
+        assert "value_timing" in line
+    else:
+        assert 0.5 < r.get("pass_frac", r["frac"]) < 1.0
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]
     c = line["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

@@ -71,38 +71,34 @@ def test_c4_state_round_trip_is_idempotent(product, c4):
     product.lib.sf3d_clean()
 
 
-@pytest.mark.parametrize("case", ["c2f60", "c3f20", "c4f20"])
-def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
-    """The single-GPU fast path (sweep + convergence decision fused through a last-block hand-off,
-    batches replayed from hipGraphs) must give exactly the bits of the plain path (separate
-    decision kernel, eager launches), and so must the link flow sums added on a second stream next to the
-    next step (default) versus inside the step (SF3D_OVERLAP_ACCEPT=0): same partial-sum order, same decisions, same sums."""
+def _launch_modes(full):
+    """The reference point is the plain path: separate decision kernels, eager launches, link sums inside the step, single sweeps,
+    k_props + k_assemble.  Against it: the defaults a user gets (fused decisions, hipGraphs, overlapped link sums and - where the grid
+    is large - the paired sweep and the layer-marching approximation kernel), and every switchable form on its own."""
+    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_APPROX_PATCH="0")
+    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_APPROX_PATCH="0")
+    auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_APPROX_PATCH")}      # the library picks sweep and launch form itself
+    modes = [base, auto,
+             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10", SF3D_APPROX_PATCH="1", SF3D_PATCH_W="10"),     # both patch kernels forced on (small grids too)
+             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_APPROX_PATCH="1", SF3D_PATCH_W="6", SF3D_OVERLAP_ACCEPT="0")]
+    if full:
+        modes += [fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"),
+                  dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0"),
+                  dict(fast, SF3D_APPROX_PATCH="1", SF3D_PATCH_W="14", SF3D_GRAPHS="0"),
+                  dict(fast, SF3D_APPROX_PATCH="1", SF3D_PATCH_W="10")]
+    return modes
+
+
+def _run_modes(case, modes, tmp_path):
     import os
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     outs = []
-    # the reference point is the plain path: separate decision kernels, eager launches, link sums inside the step, single sweeps.
-    # Against it: the defaults (fused decisions, hipGraphs, overlapped link sums, paired sweep where the grid is large), the
-    # common 2 048-block grid, the first Jacobi iteration inside k_assemble, and the paired sweep (two Jacobi iterations per pass
-    # through an LDS ring, k_sweep_pair) forced on with every patch height.  The fused variants sum their norms over another
-    # block layout: equal decisions, hence equal fields.
-    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_FUSE_FIRST_SWEEP="0", SF3D_PAIR_SWEEP="0",
-                SF3D_ASM_UNIFORM="0", SF3D_PERSISTENT="0")        # every soil row through the general assembly code, one launch per phase
-    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_FUSE_FIRST_SWEEP="0", SF3D_PAIR_SWEEP="0",
-                SF3D_PERSISTENT="0")
-    modes = [base, fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"), dict(fast, SF3D_FUSE_FIRST_SWEEP="1"),
-             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10"), dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6"),
-             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0")]
-    modes.append(dict(fast, SF3D_PERSISTENT="1"))      # the whole computeStep in one launch (k_step_persistent: grid barriers instead of kernel boundaries)
-    auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_PERSISTENT")}   # what a user gets: the library picks sweep and launch form itself
-    modes.append(auto)
-    modes.append(dict(fast, SF3D_ASM_UNIFORM="2"))      # the same two assembly kernels side by side on two streams, Courant decision after the join
-    modes.append(dict(fast, SF3D_ASM_UNIFORM="1"))      # soil rows with chunk-uniform geometry through k_assemble_uniform (kept as a measured alternative)
     for k, mode in enumerate(modes):
         out = tmp_path / f"{case}_{k}.npz"
-        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM", "SF3D_PERSISTENT"))}
+        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM", "SF3D_PERSISTENT", "SF3D_APPROX", "SF3D_PATCH"))}
         env.update(mode)
         p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
                            capture_output=True, text=True, timeout=900)
@@ -112,11 +108,25 @@ def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
     for mode, b in zip(modes[1:], outs[1:]):
         assert set(a.files) == set(b.files)
         for k in a.files:
-            if k.startswith("storage") and mode.get("SF3D_PERSISTENT") == "1":
-                # the persistent kernel reduces theta V over its own (resident-size) grid: another order of the same terms
-                assert abs(a[k] - b[k]) <= 1e-13 * abs(a[k]), k
-                continue
             assert np.array_equal(a[k], b[k]), (k, mode)
+
+
+@pytest.mark.parametrize("case", ["c2f60", "c3f20", "c4f20"])
+def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
+    """The single-GPU fast paths (sweep + convergence decision fused through a last-block hand-off, batches replayed from hipGraphs,
+    link flow sums on a second stream, two Jacobi iterations per pass through an LDS ring, node properties + soil rows in one
+    layer-marching launch) must give exactly the bits of the plain path: same partial-sum order, same decisions, same sums.
+    Four modes by default; SF3D_FULL_MATRIX=1 runs every switchable form on its own (test below)."""
+    _run_modes(case, _launch_modes(False), tmp_path)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", ["c2f60", "c3f20", "c4f20"])
+def test_launch_modes_full_matrix(case, tmp_path):
+    import os
+    if os.environ.get("SF3D_FULL_MATRIX") != "1":
+        pytest.skip("the full launch-mode matrix (10 modes x 3 cases, one process each) runs with SF3D_FULL_MATRIX=1")
+    _run_modes(case, _launch_modes(True), tmp_path)
 
 
 def test_ravone_dem_first_steps_match_oracle(product, oracle):
