@@ -241,6 +241,11 @@ struct PairGrid {
     uint32_t patchCols, patchRows;      /* NX / 64, ceil(NY / (W - 2)) */
     const uint64_t* nodeCode;           /* [N] */
     const uint64_t* chunkCode;          /* [N / 64] */
+    /* layered MASKED grids (k_sweep_pair_masked: DEM outlines, soil columns of different depth): NX x NY x NZ is the bounding grid */
+    uint32_t masked;                    /* 1: the fields below describe the graph, chunkCode is unused */
+    const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
+    const uint32_t* patchList;          /* [blocks] non-empty patches: (patch row << 12) | patch column */
+    const uint8_t* patchDepth;          /* [blocks] layers the patch (halo included) reaches */
 };
 
 struct DevView {

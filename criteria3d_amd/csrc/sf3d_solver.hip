@@ -1393,6 +1393,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 }
 
 #include "sf3d_pair.inc"        /* k_sweep_pair: two Jacobi iterations per pass through an LDS ring */
+#include "sf3d_pair_masked.inc" /* k_sweep_pair_masked: the same on layered masked grids (DEM outlines) */
 #include "sf3d_patch.inc"       /* k_approx_patch: node properties + soil rows of an approximation in one layer-marching pass */
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
@@ -1759,6 +1760,7 @@ struct DeviceSolver::Impl {
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
     uint32_t pairBlocks = 0;              /* grid of k_sweep_pair (0: the graph is no regular grid, or the paired sweep is off) */
     uint32_t patchBlocks = 0, patchW = 0; /* grid and patch height of k_approx_patch (0: off) */
+    bool pairMasked = false;              /* the paired sweep runs as k_sweep_pair_masked (layered masked grid) */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
     std::vector<Pair> pending;             /* pairs of the batch in flight, in launch order */
@@ -2047,6 +2049,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         /* paired sweep (k_sweep_pair): is the graph a regular NX x NY x NZ grid in layer-major numbering, and which neighbour
          * does every link slot of every node name?  (host logic; the same structure sf3d_get_regular_grid reports) */
         std::vector<uint64_t> pairNode, pairChunk;
+        std::vector<int32_t> pairIdxMap;            /* non-empty: the graph is a layered masked grid, not a full box */
         uint32_t pairNX = 0, pairNY = 0, pairNZ = 0;
         {
             const char* pe = getenv("SF3D_PAIR_SWEEP");
@@ -2104,6 +2107,82 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     if (same) pairChunk[q] = pairNode[(size_t)q * SF3D_CHUNK] | (1ull << 63);
                 }
             } else { pairNode.clear(); pairNX = pairNY = pairNZ = 0; }
+            /* not a full box: a LAYERED MASKED grid?  (a DEM outline with holes, soil columns of different depth - what
+             * Project3D::setCrit3DTopography builds, project3D.cpp:941-1103.)  Every node gets (layer, row, column): layer = number of Up
+             * hops to the surface, row / column from the surface node's coordinates; every link must go to one of the 26 grid neighbours. */
+            if (!regular && world_ == 1 && want != 0 && ns >= 64 && N < (1u << 28) && m.x.size() == N && m.y.size() == N) {
+                bool ok = true;
+                std::vector<int32_t> lay(N, -1), row(N, -1), colv(N, -1);
+                double cell = 0.;
+                for (int sl = 2; sl < SF3D_SLOTS; ++sl)
+                    for (uint32_t i = 0; i < ns; ++i) {
+                        const size_t e = (size_t)sl * N + i;
+                        if (kind[e] == LK_NONE) continue;
+                        const double dx = std::fabs(m.x[to[e]] - m.x[i]), dy = std::fabs(m.y[to[e]] - m.y[i]);
+                        const double d = dx > 0 ? (dy > 0 ? std::min(dx, dy) : dx) : dy;
+                        if (d > 0 && (cell == 0. || d < cell)) cell = d;
+                    }
+                ok = cell > 0.;
+                double xmin = 0, ymin = 0, ymax = 0;
+                if (ok) {
+                    xmin = m.x[0]; ymin = ymax = m.y[0];
+                    for (uint32_t i = 1; i < ns; ++i) { xmin = std::min(xmin, m.x[i]); ymin = std::min(ymin, m.y[i]); ymax = std::max(ymax, m.y[i]); }
+                    const bool northFirst = m.y[0] > m.y[ns - 1];
+                    for (uint32_t i = 0; i < ns && ok; ++i) {
+                        const double fc = (m.x[i] - xmin) / cell, fr = (northFirst ? (ymax - m.y[i]) : (m.y[i] - ymin)) / cell;
+                        const long long c = std::llround(fc), r = std::llround(fr);
+                        if (std::fabs(fc - (double)c) > 1e-6 || std::fabs(fr - (double)r) > 1e-6 || c > 60000 || r > 60000) ok = false;
+                        lay[i] = 0; row[i] = (int32_t)r; colv[i] = (int32_t)c;
+                    }
+                }
+                for (uint32_t i = ns; i < N && ok; ++i) {           /* soil nodes: below the node their Up link names (layer-major: it has a smaller index) */
+                    if (kind[i] == LK_NONE || to[i] >= i || lay[to[i]] < 0) { ok = false; break; }
+                    lay[i] = lay[to[i]] + 1; row[i] = row[to[i]]; colv[i] = colv[to[i]];
+                }
+                int32_t mr = 0, mc = 0, ml = 0;
+                if (ok) for (uint32_t i = 0; i < N; ++i) { mr = std::max(mr, row[i]); mc = std::max(mc, colv[i]); ml = std::max(ml, lay[i]); }
+                const uint32_t gNX = ok ? (uint32_t)((mc + 64) / 64 * 64) : 0, gNY = (uint32_t)mr + 1, gNZ = (uint32_t)ml + 1;
+                if (ok && ((uint64_t)gNX * gNY * gNZ > (1ull << 30) || gNZ < 2 || gNY < 6)) ok = false;
+                std::vector<int32_t> idxMap;
+                if (ok) {
+                    idxMap.assign((size_t)gNX * gNY * gNZ, -1);
+                    for (uint32_t i = 0; i < N && ok; ++i) {
+                        int32_t& cellIdx = idxMap[((size_t)lay[i] * gNY + (size_t)row[i]) * gNX + (size_t)colv[i]];
+                        if (cellIdx >= 0) ok = false;                /* two nodes in one cell */
+                        cellIdx = (int32_t)i;
+                    }
+                }
+                if (ok) {
+                    pairNode.assign(N, 0);
+                    std::atomic<bool> bad{false};
+                    parallel_for(N, [&](uint32_t a, uint32_t b) {
+                        for (uint32_t i = a; i < b && !bad.load(std::memory_order_relaxed); ++i) {
+                            uint64_t code = 0; unsigned seen = 0;
+                            for (int sl = 0; sl < SF3D_SLOTS; ++sl) {
+                                const size_t e = (size_t)sl * N + i;
+                                uint64_t nib = SF3D_PAIR_NONE;
+                                if (kind[e] != LK_NONE) {
+                                    const uint32_t j = to[e];
+                                    const int32_t dl = lay[j] - lay[i], dr = row[j] - row[i], dc = colv[j] - colv[i];
+                                    if (sl == 0) { if (dl != -1 || dr != 0 || dc != 0) bad = true; nib = SF3D_PAIR_UP; }
+                                    else if (sl == 1) { if (dl != 1 || dr != 0 || dc != 0) bad = true; nib = SF3D_PAIR_DOWN; }
+                                    else {
+                                        if (dl != 0 || dr < -1 || dr > 1 || dc < -1 || dc > 1 || (dr == 0 && dc == 0)) { bad = true; break; }
+                                        nib = (uint64_t)((dr + 1) * 3 + (dc + 1));
+                                        if (seen & (1u << nib)) bad = true;
+                                        seen |= 1u << nib;
+                                    }
+                                }
+                                code |= nib << (4 * sl);
+                            }
+                            pairNode[i] = code;
+                        }
+                    });
+                    ok = !bad;
+                }
+                if (ok) { pairNX = gNX; pairNY = gNY; pairNZ = gNZ; pairIdxMap.swap(idxMap); pairChunk.assign(nChunks, 0); }
+                else { pairNode.clear(); }
+            }
         }
 
         /* ownership + chunk lists (identity lists on one GPU) */
@@ -2172,7 +2251,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             const double sweepBytes = 152.0 * (double)v.nList * SF3D_CHUNK;
             v.ntStream = e ? (e[0] != '0') : (sweepBytes > 256.0 * 1024 * 1024);
         }
-        I.pairBlocks = 0; I.patchBlocks = 0; I.patchW = 0;
+        I.pairBlocks = 0; I.patchBlocks = 0; I.patchW = 0; I.pairMasked = false; v.pair.masked = 0;
         if (!pairNode.empty()) {
             /* the paired sweep pays where the sweep streams from HBM (ntStream: above the Infinity Cache) - below that the plain sweep
              * is cache-resident and faster; SF3D_PAIR_SWEEP=1 forces it on any regular grid (tests on small grids) */
@@ -2181,7 +2260,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             /* the layer-marching approximation kernel (k_approx_patch) shares the grid description: on wherever the paired sweep is,
              * SF3D_APPROX_PATCH=0/1 forces; water only (the heat variant of the rows lives in k_assemble) */
             const char* ae = getenv("SF3D_APPROX_PATCH");
-            const bool patchOn = !m.heat && (ae ? (ae[0] != '0') : (v.ntStream != 0));
+            const bool patchOn = pairIdxMap.empty() && !m.heat && (ae ? (ae[0] != '0') : (v.ntStream != 0));
             if (patchOn) {
                 uint32_t W = 10; if (const char* we = getenv("SF3D_PATCH_W")) W = (uint32_t)atoi(we);
                 if (W != 6 && W != 10 && W != 14) W = 10;
@@ -2200,9 +2279,38 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                 int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, I.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
                 uint32_t bestW = 0; double bestCost = 1e30;
                 const char* we = getenv("SF3D_PAIR_W");
+                /* masked grids: the non-empty patches (a patch owns rows pr (W - 2) .. + W - 3 and 64 columns) and the layers they reach */
+                std::vector<uint32_t> plist[3]; std::vector<uint8_t> pdepth[3];
+                if (!pairIdxMap.empty()) {
+                    std::vector<uint8_t> colDepth((size_t)pairNX * pairNY, 0);          /* deepest layer + 1 of every cell's column */
+                    for (uint32_t l = 0; l < pairNZ; ++l)
+                        for (size_t k = 0; k < colDepth.size(); ++k)
+                            if (pairIdxMap[(size_t)l * colDepth.size() + k] >= 0) colDepth[k] = (uint8_t)(l + 1);
+                    int wi = 0;
+                    for (uint32_t W : {6u, 10u, 14u}) {
+                        const uint32_t prs = (pairNY + W - 3) / (W - 2), pcs = pairNX / 64;
+                        for (uint32_t pr = 0; pr < prs; ++pr)
+                            for (uint32_t pc = 0; pc < pcs; ++pc) {
+                                const int64_t r0 = (int64_t)pr * (W - 2) - 1, c0 = (int64_t)pc * 64 - 1;
+                                bool any = false; uint8_t depth = 0;
+                                for (int64_t r = r0; r < r0 + (int64_t)W; ++r) {
+                                    if (r < 0 || r >= (int64_t)pairNY) continue;
+                                    for (int64_t cc = c0; cc < c0 + 66; ++cc) {
+                                        if (cc < 0 || cc >= (int64_t)pairNX) continue;
+                                        const uint8_t d = colDepth[(size_t)r * pairNX + (size_t)cc];
+                                        if (d > depth) depth = d;
+                                        if (d && r > r0 && r < r0 + (int64_t)W - 1 && cc > c0 && cc < c0 + 65) any = true;      /* an owned cell */
+                                    }
+                                }
+                                if (any) { plist[wi].push_back((pr << 12) | pc); pdepth[wi].push_back(depth); }
+                            }
+                        ++wi;
+                    }
+                }
                 for (uint32_t W : {6u, 10u, 14u}) {
                     if (pairNY < W || (we && (uint32_t)atoi(we) != W)) continue;
-                    const uint64_t blocks = (uint64_t)((pairNY + W - 3) / (W - 2)) * (pairNX / 64);
+                    const uint64_t blocks = pairIdxMap.empty() ? (uint64_t)((pairNY + W - 3) / (W - 2)) * (pairNX / 64) : (uint64_t)plist[W == 6 ? 0 : (W == 10 ? 1 : 2)].size();
+                    if (blocks == 0) continue;
                     const uint64_t resident = (uint64_t)(4 * SF3D_PAIR_WAVES / (W + 1)) * cus;     /* blocks of W + 1 waves per CU */
                     const uint64_t rounds = (blocks + resident - 1) / resident;
                     const double cost = (double)(rounds * resident) / (double)blocks * (double)W / (double)(W - 2);
@@ -2217,6 +2325,17 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                     v.pair.patchCols = pairNX / 64; v.pair.patchRows = (pairNY + bestW - 3) / (bestW - 2);
                     v.pair.nodeCode = dn; v.pair.chunkCode = dq;
                     I.pairBlocks = v.pair.patchCols * v.pair.patchRows;
+                    v.pair.masked = 0; I.pairMasked = false;
+                    if (!pairIdxMap.empty()) {
+                        const int wi = bestW == 6 ? 0 : (bestW == 10 ? 1 : 2);
+                        int32_t* dm; uint32_t* dl; uint8_t* dd;
+                        HIP_TRY(dev_alloc(I.allocs, dm, pairIdxMap.size())); HIP_TRY(dev_alloc(I.allocs, dl, plist[wi].size())); HIP_TRY(dev_alloc(I.allocs, dd, pdepth[wi].size()));
+                        HIP_TRY(hipMemcpy(dm, pairIdxMap.data(), pairIdxMap.size() * 4, hipMemcpyHostToDevice));
+                        HIP_TRY(hipMemcpy(dl, plist[wi].data(), plist[wi].size() * 4, hipMemcpyHostToDevice));
+                        HIP_TRY(hipMemcpy(dd, pdepth[wi].data(), pdepth[wi].size(), hipMemcpyHostToDevice));
+                        v.pair.masked = 1; v.pair.idxMap = dm; v.pair.patchList = dl; v.pair.patchDepth = dd;
+                        I.pairBlocks = (uint32_t)plist[wi].size(); I.pairMasked = true;
+                    }
                 }
             }
         }
@@ -3029,6 +3148,17 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             for (uint32_t k = 0; k < nPairs; ++k) {
                 if (k == singleAfter) timed(KID_SWEEP, [&] { if (v.ntStream) hipLaunchKernelGGL((k_sweep<1, true>), grid, block, 0, st, v); else hipLaunchKernelGGL((k_sweep<1, false>), grid, block, 0, st, v); });
                 timed(KID_SWEEP_PAIR, [&] {
+                    if (I.pairMasked) {
+                        switch (v.pair.W * 2 + (v.ntStream ? 1 : 0)) {
+                            case 12: hipLaunchKernelGGL((k_sweep_pair_masked<6, false>), pgr, pbl, 0, st, v); break;
+                            case 13: hipLaunchKernelGGL((k_sweep_pair_masked<6, true>), pgr, pbl, 0, st, v); break;
+                            case 20: hipLaunchKernelGGL((k_sweep_pair_masked<10, false>), pgr, pbl, 0, st, v); break;
+                            case 21: hipLaunchKernelGGL((k_sweep_pair_masked<10, true>), pgr, pbl, 0, st, v); break;
+                            case 28: hipLaunchKernelGGL((k_sweep_pair_masked<14, false>), pgr, pbl, 0, st, v); break;
+                            default: hipLaunchKernelGGL((k_sweep_pair_masked<14, true>), pgr, pbl, 0, st, v); break;
+                        }
+                        return;
+                    }
                     switch (v.pair.W * 2 + (v.ntStream ? 1 : 0)) {
                         case 12: hipLaunchKernelGGL((k_sweep_pair<6, false>), pgr, pbl, 0, st, v); break;
                         case 13: hipLaunchKernelGGL((k_sweep_pair<6, true>), pgr, pbl, 0, st, v); break;

@@ -205,6 +205,40 @@ def test_paired_sweep_on_awkward_grids(product, shape, w):
     assert ca == cb
 
 
+@pytest.mark.parametrize("which,w", [("dem_window", "10"), ("project_window", "6"), ("random_holes", "14"), ("random_holes_wide", "10")])
+def test_paired_sweep_on_masked_grids(product, which, w):
+    """k_sweep_pair_masked against k_sweep on layered MASKED grids - DEM outlines with holes, soil columns that end at different depths,
+    a random subset of the lateral links, both row orientations: same H, Se, accepted steps and counters, bit for bit"""
+    from pathlib import Path
+    from tests.scenarios import env, ravone_project_model
+    if which == "dem_window":
+        m = cm.dem_model(np.load(Path(__file__).resolve().parent / "golden" / "ravone_dem_window_72x72.npy"))
+    elif which == "project_window":
+        m = ravone_project_model((980, 1060, 330, 420))
+    elif which == "random_holes":
+        m = cm.random_model(23, nx=70, ny=45, nz=5)
+    else:
+        m = cm.random_model(5, nx=150, ny=20, nz=4)
+    assert m.ns >= 64
+    res = []
+    for pair in ("0", "1"):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w):
+            product.check(product.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(product, m)
+            product.check(product.lib.sf3d_kernel_timing(1), "timing")       # event statistics tell which sweep kernel ran
+            _, d0 = cm.run_hour(product, m, 30.0, max_steps=120)
+            _, d1 = cm.run_hour(product, m, 0.0, max_steps=60)
+            stats = product.kernel_stats()
+            product.lib.sf3d_kernel_timing(0)
+            assert (stats["k_sweep_pair"][0] > 0) == (pair == "1") and (pair == "1" or stats["k_sweep"][0] > 0), stats
+            res.append((np.array(d0 + d1), cm.snapshot(product, m), product.counters()))
+        product.lib.sf3d_clean()
+    (da, sa, ca), (db, sb, cb) = res
+    assert np.array_equal(da, db)
+    assert np.array_equal(sa["H"], sb["H"]) and np.array_equal(sa["Se"], sb["Se"])
+    assert ca == cb
+
+
 def test_paired_sweep_with_heat_and_with_the_compat_rows(product):
     """the paired sweep next to the other users of the water system: the coupled heat step (thermal fluxes in the water rows, saved
     water fluxes read from the matrix) and the quirk-1 emulation (rows stored raw, normalised by k_compat_rows) - bitwise against

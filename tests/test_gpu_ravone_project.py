@@ -46,30 +46,32 @@ def test_project_window_two_hours_match_oracle(product, oracle):
 
 
 def test_project_full_size_runoff_regime_matches_oracle(product, oracle):
-    """The whole project (5.5 M nodes).  The product alone runs the 25 mm hour and the start of the dry hour (several hundred steps,
-    down to the minimum time step); its state - H of every node and the adaptive time step - is then handed to BOTH libraries
-    through the state setters (the application's own restart path, criteria3DProject.cpp:2934-3123), and both take the next 300
-    computeStep calls of the runoff regime from there: H within 1e-6, identical accepted dt, identical counters, restore-best
-    steps among them."""
+    """The whole project (5.85 M nodes, 422 282 columns).  The product alone runs the 25 mm hour (1 650 computeStep calls, down to
+    dt = 1 s; 6 s of GPU time - the oracle would need an hour); its state at the end of that hour - H of every node and the adaptive
+    time step - is then handed to BOTH libraries through the state setters (the application's own restart path,
+    criteria3DProject.cpp:2934-3123), and both take the first computeStep calls of the dry hour from there, where the time step falls
+    to its minimum and restore-best steps occur: H within 1e-6, identical accepted dt, identical counters.  120 calls by default (the
+    oracle needs ~2 s per call at this size), 300 with SF3D_LONG_TESTS=1."""
+    import os
+    steps = 300 if os.environ.get("SF3D_LONG_TESTS") == "1" else 120
     m = ravone_project_model(None)
     assert m.ns == 422282 and m.n > 5_000_000
     product.check(product.lib.sf3d_reset_solver_state(), "reset")
     cm.build(product, m)
-    cm.run_hour(product, m, 25.0)
-    cm.run_hour(product, m, 0.0, max_steps=400)
+    n0, _ = cm.run_hour(product, m, 25.0)
     warm = product.counters()
     H0, dt0 = product.total_potential(0, m.n), product.lib.sf3d_get_time_step()
-    assert np.all(np.isfinite(H0)) and warm["accepted"] > 600
+    assert np.all(np.isfinite(H0)) and n0 > 1000 and warm["courant_rejections"] > 0
     dts = {}
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64)
+        cm.build(sf, m, threads=32)
         sf.set_total_potential_bulk(0, H0)
         sf.check(sf.lib.sf3d_set_time_step(dt0), "set_time_step")
         sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
-        _, dts[sf.backend] = cm.run_hour(sf, m, 0.0, max_steps=300)
+        _, dts[sf.backend] = cm.run_hour(sf, m, 0.0, max_steps=steps)
     np.testing.assert_allclose(dts[product.backend], dts[oracle.backend], rtol=1e-12)
-    _compare(product, oracle, m, "300 steps")
+    _compare(product, oracle, m, f"{steps} steps")
     c = oracle.counters()
-    assert c["accepted"] == 300 and c["restores"] > 0, c
+    assert c["accepted"] == steps and c["restores"] > 0, c
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
