@@ -48,8 +48,7 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.
 # algorithmic bytes per node per launch (DESIGN.md "Algorithmic bytes"): what ONE launch has to move.
 # k_sweep_pair makes one pass for two Jacobi iterations: 80 coefficients + 40 index + 8 b + 8 z + 8 x + 8 x' + 8 x'' = 160 B/node
 # (the two single sweeps it replaces would move 2 x 152: reported separately as `equivalent_sweep_frac`, never as `frac`)
-ALGO_BYTES = {"k_sweep": 152, "k_sweep_pair": 160, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288,
-              "k_approx_patch": 441 - 84}
+ALGO_BYTES = {"k_sweep": 152, "k_sweep_pair": 160, "k_props": 75, "k_assemble": 282, "k_post": 84, "k_restore": 101, "k_accept": 288}
 EQUIVALENT_SWEEP_BYTES = {"k_sweep_pair": 2 * 152}
 # whole-step model of SURVEY.md 8d: bytes = N (B_J n_J + 441 n_A + 336 n_S + 117 n_R); with the paired sweep a Jacobi iteration
 # costs half a pass (80 B/node)

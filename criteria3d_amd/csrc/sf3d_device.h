@@ -305,6 +305,6 @@ struct DevView {
 };
 
 /* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */
-enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_APPROX_PATCH, KID_COUNT };
+enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_COUNT };
 
 #endif

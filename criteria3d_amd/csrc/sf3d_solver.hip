@@ -1394,7 +1394,6 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
 
 #include "sf3d_pair.inc"        /* k_sweep_pair: two Jacobi iterations per pass through an LDS ring */
 #include "sf3d_pair_masked.inc" /* k_sweep_pair_masked: the same on layered masked grids (DEM outlines) */
-#include "sf3d_patch.inc"       /* k_approx_patch: node properties + soil rows of an approximation in one layer-marching pass */
 
 __device__ __forceinline__ void balance_terms(const DevView& v, const Ctrl* c, uint32_t i, double H, double z,
                                               double Se, double& st, double& sk)
@@ -1617,7 +1616,7 @@ template <class F> void parallel_for(uint32_t n, F f)
     for (auto& t : th) t.join();
 }
 
-const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept", "k_sweep_pair", "k_approx_patch"};
+const char* kKernelNames[KID_COUNT] = {"k_props", "k_assemble", "k_sweep", "k_post", "k_restore", "k_accept", "k_sweep_pair"};
 
 }  // namespace
 
@@ -1759,7 +1758,6 @@ struct DeviceSolver::Impl {
     std::vector<std::pair<const void*, uint32_t>> residentBlocks;   /* kernel -> blocks resident at once (occupancy x CUs) */
     int residentGrids = -1;               /* SF3D_RESIDENT_GRIDS=0: every kernel with the common 2 048-block grid */
     uint32_t pairBlocks = 0;              /* grid of k_sweep_pair (0: the graph is no regular grid, or the paired sweep is off) */
-    uint32_t patchBlocks = 0, patchW = 0; /* grid and patch height of k_approx_patch (0: off) */
     bool pairMasked = false;              /* the paired sweep runs as k_sweep_pair_masked (layered masked grid) */
     uint64_t stepSeq = 0;
     struct Pair { hipEvent_t a, b; int kid; };
@@ -2251,30 +2249,12 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             const double sweepBytes = 152.0 * (double)v.nList * SF3D_CHUNK;
             v.ntStream = e ? (e[0] != '0') : (sweepBytes > 256.0 * 1024 * 1024);
         }
-        I.pairBlocks = 0; I.patchBlocks = 0; I.patchW = 0; I.pairMasked = false; v.pair.masked = 0;
+        I.pairBlocks = 0; I.pairMasked = false; v.pair.masked = 0;
         if (!pairNode.empty()) {
             /* the paired sweep pays where the sweep streams from HBM (ntStream: above the Infinity Cache) - below that the plain sweep
              * is cache-resident and faster; SF3D_PAIR_SWEEP=1 forces it on any regular grid (tests on small grids) */
             const char* pe = getenv("SF3D_PAIR_SWEEP");
             const bool on = pe ? (pe[0] != '0') : (v.ntStream != 0);
-            /* the layer-marching approximation kernel (k_approx_patch) shares the grid description: on wherever the paired sweep is,
-             * SF3D_APPROX_PATCH=0/1 forces; water only (the heat variant of the rows lives in k_assemble) */
-            const char* ae = getenv("SF3D_APPROX_PATCH");
-            const bool patchOn = pairIdxMap.empty() && !m.heat && (ae ? (ae[0] != '0') : (v.ntStream != 0));
-            if (patchOn) {
-                uint32_t W = 10; if (const char* we = getenv("SF3D_PATCH_W")) W = (uint32_t)atoi(we);
-                if (W != 6 && W != 10 && W != 14) W = 10;
-                while (W > 6 && pairNY < W) W -= 4;
-                if (pairNY >= W) { I.patchW = W; I.patchBlocks = (pairNX / 64) * ((pairNY + W - 3) / (W - 2)); }
-            }
-            if (I.patchBlocks && !on) {          /* the grid description alone (no paired sweep) */
-                uint64_t *dn, *dq;
-                HIP_TRY(dev_alloc(I.allocs, dn, pairNode.size())); HIP_TRY(dev_alloc(I.allocs, dq, pairChunk.size()));
-                HIP_TRY(hipMemcpy(dn, pairNode.data(), pairNode.size() * 8, hipMemcpyHostToDevice));
-                HIP_TRY(hipMemcpy(dq, pairChunk.data(), pairChunk.size() * 8, hipMemcpyHostToDevice));
-                v.pair.NX = pairNX; v.pair.NY = pairNY; v.pair.NZ = pairNZ; v.pair.W = 0; v.pair.patchCols = pairNX / 64; v.pair.patchRows = 0;
-                v.pair.nodeCode = dn; v.pair.chunkCode = dq;
-            }
             if (on) {
                 int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, I.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
                 uint32_t bestW = 0; double bestCost = 1e30;
@@ -2432,7 +2412,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         }
         HIP_TRY(dev_alloc(I.allocs, v.flow, N)); HIP_TRY(dev_alloc(I.allocs, v.bflowRate, N));
         HIP_TRY(dev_alloc(I.allocs, v.bflowSum, N));
-        {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, std::max(I.pairBlocks, I.patchBlocks)) + 8;
+        {   const size_t np = std::max<size_t>(v.nb + v.nbSurf, I.pairBlocks) + 8;
             HIP_TRY(dev_alloc(I.allocs, v.part0, np)); HIP_TRY(dev_alloc(I.allocs, v.part1, np)); }
         HIP_TRY(dev_alloc(I.allocs, v.arrive, 16 * 17)); HIP_TRY(hipMemset(v.arrive, 0, 16 * 17 * sizeof(unsigned int)));
         HIP_TRY(dev_alloc(I.allocs, v.gridBar, 16)); HIP_TRY(hipMemset(v.gridBar, 0, 16 * sizeof(unsigned int)));
@@ -3035,9 +3015,6 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     const bool pairOn = fused && I.pairBlocks != 0 && !linealOn;   /* k_sweep_pair instead of k_sweep */
     const dim3 pgrid(I.pushBlocks ? I.pushBlocks : 1);
     hipStream_t st = I.stream;
-    /* node properties + soil rows of an approximation in one layer-marching launch (k_approx_patch), surface rows + Courant decision
-     * by k_assemble's surface blocks right after it */
-    const bool patchOn = fused && I.patchBlocks != 0 && !heatOn;
 
     /* mode 2 samples: the sweeps of every 8th computeStep carry HIP events (eager launches); the other
      * steps replay hipGraphs, so the measurement costs ~1 % instead of ~6 % */
@@ -3103,21 +3080,6 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     static const bool asmNtOff = getenv("SF3D_ASM_NT") && getenv("SF3D_ASM_NT")[0] == '0';      /* tuning: cacheable stores of the rows */
     const bool asmNT = v.ntStream && !asmNtOff;
     auto enqueue_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) {
-        if (withHead && patchOn) {
-            const dim3 agr(I.patchBlocks), abl((I.patchW + 1) * 64);
-            timed(KID_APPROX_PATCH, [&] {
-                switch (I.patchW * 2 + (asmNT ? 1 : 0)) {
-                    case 12: hipLaunchKernelGGL((k_approx_patch<6, false>), agr, abl, 0, st, v); break;
-                    case 13: hipLaunchKernelGGL((k_approx_patch<6, true>), agr, abl, 0, st, v); break;
-                    case 20: hipLaunchKernelGGL((k_approx_patch<10, false>), agr, abl, 0, st, v); break;
-                    case 21: hipLaunchKernelGGL((k_approx_patch<10, true>), agr, abl, 0, st, v); break;
-                    case 28: hipLaunchKernelGGL((k_approx_patch<14, false>), agr, abl, 0, st, v); break;
-                    default: hipLaunchKernelGGL((k_approx_patch<14, true>), agr, abl, 0, st, v); break;
-                }
-            });
-            /* the surface rows (runoff + infiltration from above) and the Courant decision: k_assemble's surface blocks alone */
-            timed(KID_ASSEMBLE, [&] { if (asmNT) hipLaunchKernelGGL((k_assemble<true, true, false>), dim3(v.nbSurf), block, 0, st, v); else hipLaunchKernelGGL((k_assemble<true, false, false>), dim3(v.nbSurf), block, 0, st, v); });
-        } else
         if (withHead) {
             if (!skipProps) enqueue_props();
             if (heatOn && I.useFused) timed(KID_ASSEMBLE, [&] { hipLaunchKernelGGL((k_assemble<true, false, true>), dim3(v.nbSurf + v.nbSoil), block, 0, st, v); });
@@ -3215,7 +3177,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
     };
     auto launch_batch = [&](bool withHead, bool withTail, bool skipProps, uint32_t chunk) -> hipError_t {
         if (!I.useGraphs || timedStep || I.rcclMode) { enqueue_batch(withHead, withTail, skipProps, chunk); return hipSuccess; }   /* (RCCL calls are queued eagerly) */
-        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u) | (patchOn ? 1u << 25 : 0u);
+        const uint32_t key = (withHead ? 1u : 0u) | (withTail ? 2u : 0u) | (chunk << 2) | (skipProps ? 1u << 20 : 0u) | (overlap ? 1u << 21 : 0u) | (pairOn ? 1u << 22 : 0u) | (linealOn ? 1u << 23 : 0u);
         for (auto& g : I.graphs) if (g.first == key) return hipGraphLaunch(g.second, st);
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -3248,7 +3210,7 @@ sf3d_error_t DeviceSolver::step(HostModel& m, ParamsHost& p, double maxTimeStep,
             /* attribute event pairs only to launches that really ran: how many of each kernel ran
              * comes from the device counters; guarded no-op launches are the shortest of a group */
             uint64_t ran[KID_COUNT];
-            ran[KID_PROPS] = ran[KID_ASSEMBLE] = ran[KID_APPROX_PATCH] = c.counters[2] - before[2];
+            ran[KID_PROPS] = ran[KID_ASSEMBLE] = c.counters[2] - before[2];
             ran[KID_SWEEP] = pairOn ? c.singleLaunches - singleBefore : c.counters[3] - before[3];
             ran[KID_SWEEP_PAIR] = c.pairLaunches - pairBefore;
             ran[KID_POST] = c.counters[7] - before[7];

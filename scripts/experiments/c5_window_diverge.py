@@ -13,6 +13,9 @@ from tests.scenarios import ravone_project_model
 every = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 win = tuple(int(v) for v in sys.argv[3:7]) if len(sys.argv) > 6 else (72, 200, 300, 428)
+max_steps = int(sys.argv[7]) if len(sys.argv) > 7 else 10**9
+fine_from = int(sys.argv[8]) if len(sys.argv) > 8 else 10**9      # from this step on: compare after every step
+was_equal = True
 m = ravone_project_model(win)
 index = m.meta["index"]
 pos = np.full((m.n, 3), -1)
@@ -33,12 +36,16 @@ for h, mm in enumerate((25.0, 0.0)):
         if dg != do:
             print(f"step {k}: accepted dt differs {dg} vs {do}", flush=True); sys.exit(0)
         t += dg; k += 1
-        if k % every == 0 or t >= 3600.0:
+        if k >= max_steps: sys.exit(0)
+        if k % every == 0 or t >= 3600.0 or k >= fine_from:
             Hg, Ho = g.total_potential(0, m.n), o.total_potential(0, m.n)
             rel = np.abs(Hg - Ho) / np.maximum(np.abs(Ho), 1e-9)
             i = int(np.argmax(rel))
             cg, co = g.counters(), o.counters()
             same = all(cg[q] == co[q] for q in ("attempts", "approximations", "sweeps", "courant_rejections", "restores"))
+            if was_equal and not same:
+                was_equal = False
+                print(f"  !! counters first differ at step {k}: gpu {cg} oracle {co}", flush=True)
             print(f"step {k} h{h} t={t:.1f} dt={dg:.4f} max rel {rel[i]:.3e} at node {i} (layer,row,col)={pos[i].tolist()} btype={m.btype[i]} "
                   f"Hg={Hg[i]:.9f} Ho={Ho[i]:.9f} z={m.z[i]:.4f} counters_equal={same} sweeps={cg['sweeps']} restores={cg['restores']} wall={time.time()-t0:.0f}s", flush=True)
             while levels and rel[i] > levels[0]:

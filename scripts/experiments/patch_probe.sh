@@ -1,13 +1,13 @@
 #!/bin/bash
 # k_approx_patch against k_props + k_assemble: bitwise equality on C3/C4 F20 (scripts/run_case.py) and per-kernel times (bench --time-all-kernels)
-out=gpurun_out/${1:-patch}; mkdir -p $out
+out=gpurun_out/${1:-patch}; mkdir -p $out; big=/tmp/patch_probe_npz; mkdir -p $big
 for case in c2f60 c3f20 c4f20; do
-  SF3D_APPROX_PATCH=0 python scripts/run_case.py $case $out/${case}_off.npz
+  SF3D_APPROX_PATCH=0 python scripts/run_case.py $case $big/${case}_off.npz
   for w in 6 10 14; do
-    SF3D_APPROX_PATCH=1 SF3D_PATCH_W=$w python scripts/run_case.py $case $out/${case}_on$w.npz
+    SF3D_APPROX_PATCH=1 SF3D_PATCH_W=$w python scripts/run_case.py $case $big/${case}_on$w.npz
     python - <<PY
 import numpy as np
-a=np.load("$out/${case}_off.npz"); b=np.load("$out/${case}_on$w.npz")
+a=np.load("$big/${case}_off.npz"); b=np.load("$big/${case}_on$w.npz")
 bad=[k for k in a.files if not np.array_equal(a[k],b[k])]
 print("$case W=$w", "BITWISE EQUAL" if not bad else ("DIFFERENT: %s" % bad), flush=True)
 for k in bad[:4]:

@@ -29,11 +29,13 @@ elif case == "het":
     m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
 elif case == "ragged":
     m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
-elif case == "ravone":
-    from criteria3d_amd import esri
-    m, plan = cm.dem_model_fast(esri.load_dem_fixture(Path(__file__).resolve().parent.parent / "tests" / "golden" / "ravone_dem_519x1208.npz")[0]), [(20.0, 3)]
+elif case == "ravone":           # BASELINE config 5 as specified: the Ravone project (criteria3d_amd/project3d.py), 5.85 M nodes
+    from tests.scenarios import ravone_project_model
+    m, plan = ravone_project_model(None), [(20.0, 3)]
 elif case == "random":
     m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
+elif case == "c4f20h0":           # BASELINE config 4's cut: 512 x 512 x 20 in 8 row strips, hour 0 of F20 (22 steps)
+    m, plan = cm.catchment_model(512, 512, 20), [20.0]
 elif case == "heat":
     m, plan = cm.with_heat_surface(cm.catchment_model(40, 48, 6, heterogeneous=True)), [4.0, 0.0]
 else:
@@ -41,7 +43,7 @@ else:
 heat = cm.Heat(water=True, latent=True, save_mode=0) if case == "heat" else None
 # a throw-away model first: re-initialisation must drop the windows, re-export and re-connect
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-if case != "ravone":
+if case not in ("ravone", "c4f20h0"):
     cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
     cm.run_hour(sf, m, 5.0, max_steps=2)
     sf.check(sf.lib.sf3d_reset_solver_state(), "reset")

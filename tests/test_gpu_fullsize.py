@@ -72,20 +72,18 @@ def test_c4_state_round_trip_is_idempotent(product, c4):
 
 
 def _launch_modes(full):
-    """The reference point is the plain path: separate decision kernels, eager launches, link sums inside the step, single sweeps,
-    k_props + k_assemble.  Against it: the defaults a user gets (fused decisions, hipGraphs, overlapped link sums and - where the grid
-    is large - the paired sweep and the layer-marching approximation kernel), and every switchable form on its own."""
-    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_APPROX_PATCH="0")
-    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_APPROX_PATCH="0")
-    auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_APPROX_PATCH")}      # the library picks sweep and launch form itself
+    """The reference point is the plain path: separate decision kernels, eager launches, link sums inside the step, single sweeps.
+    Against it: the defaults a user gets (fused decisions, hipGraphs, overlapped link sums and - where the grid is large - the
+    paired sweep), and every switchable form on its own."""
+    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0")
+    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0")
+    auto = {k: v for k, v in fast.items() if k != "SF3D_PAIR_SWEEP"}      # the library picks sweep and launch form itself
     modes = [base, auto,
-             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10", SF3D_APPROX_PATCH="1", SF3D_PATCH_W="10"),     # both patch kernels forced on (small grids too)
-             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_APPROX_PATCH="1", SF3D_PATCH_W="6", SF3D_OVERLAP_ACCEPT="0")]
+             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10"),     # the paired sweep forced on (small grids too)
+             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_OVERLAP_ACCEPT="0")]
     if full:
         modes += [fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"),
-                  dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0"),
-                  dict(fast, SF3D_APPROX_PATCH="1", SF3D_PATCH_W="14", SF3D_GRAPHS="0"),
-                  dict(fast, SF3D_APPROX_PATCH="1", SF3D_PATCH_W="10")]
+                  dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0")]
     return modes
 
 
@@ -98,7 +96,7 @@ def _run_modes(case, modes, tmp_path):
     outs = []
     for k, mode in enumerate(modes):
         out = tmp_path / f"{case}_{k}.npz"
-        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM", "SF3D_PERSISTENT", "SF3D_APPROX", "SF3D_PATCH"))}
+        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM"))}
         env.update(mode)
         p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
                            capture_output=True, text=True, timeout=900)
@@ -114,8 +112,7 @@ def _run_modes(case, modes, tmp_path):
 @pytest.mark.parametrize("case", ["c2f60", "c3f20", "c4f20"])
 def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
     """The single-GPU fast paths (sweep + convergence decision fused through a last-block hand-off, batches replayed from hipGraphs,
-    link flow sums on a second stream, two Jacobi iterations per pass through an LDS ring, node properties + soil rows in one
-    layer-marching launch) must give exactly the bits of the plain path: same partial-sum order, same decisions, same sums.
+    link flow sums on a second stream, two Jacobi iterations per pass through an LDS ring) must give exactly the bits of the plain path: same partial-sum order, same decisions, same sums.
     Four modes by default; SF3D_FULL_MATRIX=1 runs every switchable form on its own (test below)."""
     _run_modes(case, _launch_modes(False), tmp_path)
 
@@ -125,47 +122,22 @@ def test_launch_modes_are_bitwise_equivalent(case, tmp_path):
 def test_launch_modes_full_matrix(case, tmp_path):
     import os
     if os.environ.get("SF3D_FULL_MATRIX") != "1":
-        pytest.skip("the full launch-mode matrix (10 modes x 3 cases, one process each) runs with SF3D_FULL_MATRIX=1")
+        pytest.skip("the full launch-mode matrix (8 modes x 3 cases, one process each) runs with SF3D_FULL_MATRIX=1")
     _run_modes(case, _launch_modes(True), tmp_path)
 
 
-def test_ravone_dem_first_steps_match_oracle(product, oracle):
-    """BASELINE config 5's grid at full size: the Ravone DEM (422 282 valid cells of 4 m, 14 soil layers of varying depth,
-    5.09 M nodes, irregular outline) through product and oracle for the first computeStep calls of a 20 mm/h hour - mixed
-    chunk descriptors (holes, short columns) at scale."""
-    from pathlib import Path
-    from criteria3d_amd import esri
-    dem, _ = esri.load_dem_fixture(Path(__file__).resolve().parent / "golden" / "ravone_dem_519x1208.npz")
-    m = cm.dem_model_fast(dem)
+def test_ravone_project_coupled_heat_first_step(product, oracle):
+    """BASELINE config 5 as specified - the Ravone project (DEM + soil map + soil database + land use, criteria3d_amd/project3d.py)
+    with coupled heat transport - at full size: one computeStep, a 600 s water step and its heat steps, on 5.85 M nodes, every top
+    soil cell an atmosphere boundary.  (The water-only trajectory at this size is tests/test_gpu_ravone_project.py.  The oracle runs
+    its loops on 32 threads here; the first step has no ponded water, so the reference's racy ponded-evaporation write is not reached.)"""
+    from tests.scenarios import ravone_project_model
+    m = cm.with_heat_surface(ravone_project_model(None))
     assert m.n > 5_000_000
-    for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64)
-    gs, gd = cm.run_hour(product, m, 20.0, max_steps=4)
-    os_, od = cm.run_hour(oracle, m, 20.0, max_steps=4)
-    np.testing.assert_allclose(gd, od, rtol=1e-12)
-    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
-    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6
-    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6
-    assert abs(g["storage"] - o["storage"]) <= 1e-6 * abs(o["storage"])
-    gc, oc = product.counters(), oracle.counters()
-    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
-        assert gc[k] == oc[k], (k, gc, oc)
-    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
-
-
-def test_ravone_dem_coupled_heat_first_step(product, oracle):
-    """the same grid with coupled heat transport (BASELINE config 5): one computeStep - a 600 s water step and its two heat
-    steps - on 5.09 M nodes, every top soil cell an atmosphere boundary.  (The oracle runs its loops on 64 threads here; the
-    first step has no ponded water, so the reference's racy ponded-evaporation write is not reached.)"""
-    from pathlib import Path
-    from criteria3d_amd import esri
-    dem, _ = esri.load_dem_fixture(Path(__file__).resolve().parent / "golden" / "ravone_dem_519x1208.npz")
-    m = cm.with_heat_surface(cm.dem_model_fast(dem))
     heat = cm.Heat(water=True, latent=True, save_mode=0)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64, heat=heat)
+        cm.build(sf, m, threads=32, heat=heat)
         cm.apply_heat_forcing(sf, m, 0)
     _, gd = cm.run_hour(product, m, 2.0, max_steps=1)
     _, od = cm.run_hour(oracle, m, 2.0, max_steps=1)

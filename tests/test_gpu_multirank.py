@@ -44,14 +44,16 @@ def oracle_reference(oracle, case):
     elif case == "het":
         m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
     elif case == "ravone":
-        from criteria3d_amd import esri
-        m, plan = cm.dem_model_fast(esri.load_dem_fixture(ROOT / "tests" / "golden" / "ravone_dem_519x1208.npz")[0]), [(20.0, 3)]
+        from tests.scenarios import ravone_project_model
+        m, plan = ravone_project_model(None), [(20.0, 3)]
     elif case == "random":
         m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
+    elif case == "c4f20h0":
+        m, plan = cm.catchment_model(512, 512, 20), [20.0]
     else:
         m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
     oracle.lib.sf3d_reset_solver_state()
-    cm.build(oracle, m, threads=64 if case == "ravone" else 1)
+    cm.build(oracle, m, threads=32 if case in ("ravone", "c4f20h0") else 1)
     out = []
     for item in plan:
         mm, mx = item if isinstance(item, tuple) else (item, None)
@@ -61,7 +63,8 @@ def oracle_reference(oracle, case):
 
 
 @pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29611), (3, "c2f60", 29612), (4, "het", 29613), (2, "ragged", 29614), (3, "random", 29615),
-                                             (4, "ravone", 29616)])      # the real 5.09 M-node DEM cut into four strips
+                                             (4, "ravone", 29616),       # the Ravone project (5.85 M nodes, irregular outline) cut into four strips
+                                             (8, "c4f20h0", 29617)])     # BASELINE config 4's cut: C4 in eight strips, hour 0 of F20
 def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
     ranks = run_ranks(world, case, tmp_path, port)
     m, ref = oracle_reference(oracle, case)
