@@ -122,7 +122,7 @@ def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     m = cm.catchment_model(256, 256, 15)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64)
+        cm.build(sf, m, threads=16)
     res = []
     for sf in (product, oracle):
         n0, d0 = cm.run_hour(sf, m, 60.0)
@@ -147,7 +147,7 @@ def test_c4_f20_all_six_hours_match_oracle(product, oracle):
     m = cm.catchment_model(512, 512, 20)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64)
+        cm.build(sf, m, threads=16)
     steps = []
     for h in range(6):
         mm = cm.FORCINGS["F20"](h)

@@ -19,7 +19,7 @@ def test_c4_hour0_matches_oracle(product, oracle, c4):
     m = c4
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=64)
+        cm.build(sf, m, threads=16)
     gs, gd = cm.run_hour(product, m, 20.0)
     g = cm.snapshot(product, m)
     os_, od = cm.run_hour(oracle, m, 20.0)

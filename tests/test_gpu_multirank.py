@@ -53,7 +53,7 @@ def oracle_reference(oracle, case):
     else:
         m, plan = cm.ragged_model(9, 24, 4), [10.0, 0.0]
     oracle.lib.sf3d_reset_solver_state()
-    cm.build(oracle, m, threads=32 if case in ("ravone", "c4f20h0") else 1)
+    cm.build(oracle, m, threads=16 if case in ("ravone", "c4f20h0") else 1)
     out = []
     for item in plan:
         mm, mx = item if isinstance(item, tuple) else (item, None)
