@@ -18,8 +18,9 @@ env = sc.env
 
 
 FLOW_RTOL = {"up": 1e-5, "down": 1e-5, "lateral_max": 1e-3, "lateral_sum": 1e-3, "lateral_in": 1e-3, "lateral_out": 1e-3}
-# per element, for the sums above 1e-3 of the largest of their kind (set from the measured values, profiles/README.md "flow sums")
-FLOW_ELEMENT_RTOL = {"up": 1e-2, "down": 1e-2, "lateral_max": 0.5, "lateral_sum": 0.5, "lateral_in": 0.5, "lateral_out": 0.5}
+# per element, for the sums above 1e-3 of the largest of their kind.  Measured (gpurun_out/r03f/flow_diag.txt, profiles/README.md):
+# up / down 2.6e-4 (C2 F20) ... 7e-9, laterals 9.7e-4 (lateral_sum, C2 F20: a sum of eight terms of both signs) ... 3e-8
+FLOW_ELEMENT_RTOL = {"up": 1e-3, "down": 1e-3, "lateral_max": 1e-3, "lateral_sum": 3e-3, "lateral_in": 1e-3, "lateral_out": 1e-3}
 
 
 def flows_close(a, b, what):
@@ -118,7 +119,7 @@ def _snap_close(g, o, tag, se_tol=1e-6, long_run=False):
 
 def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     """BASELINE config 3 in its own regime: 256x256x15, 60 mm in hour 0 - St-Venant runoff with Courant
-    rejections coupled to the subsurface - then the first 150 steps of hour 1 (dt pinned at dtmin, restore-best every step)."""
+    rejections coupled to the subsurface - then the first 1 000 steps of hour 1 (dt pinned at dtmin, restore-best every step)."""
     m = cm.catchment_model(256, 256, 15)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
@@ -127,17 +128,17 @@ def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     for sf in (product, oracle):
         n0, d0 = cm.run_hour(sf, m, 60.0)
         s0 = cm.snapshot(sf, m)
-        n1, d1 = cm.run_hour(sf, m, 0.0, max_steps=150)
+        n1, d1 = cm.run_hour(sf, m, 0.0, max_steps=1000)
         res.append((d0, s0, d1, cm.snapshot(sf, m), sf.counters()))
     (gd0, gs0, gd1, gs1, gc), (od0, os0, od1, os1, oc) = res
     assert len(gd0) == len(od0) == 76                     # step counts are grid-size independent on this catchment
     np.testing.assert_allclose(gd0, od0, rtol=1e-12)
     np.testing.assert_allclose(gd1, od1, rtol=1e-12)
     _snap_close(gs0, os0, "C3 F60 h0")
-    _snap_close(gs1, os1, "C3 F60 h1[:150]")
+    _snap_close(gs1, os1, "C3 F60 h1[:1000]", se_tol=1e-5, long_run=True)
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
-    assert gc["courant_rejections"] > 0 and gc["restores"] > 0
+    assert gc["courant_rejections"] > 0 and gc["restores"] >= 900
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 

@@ -54,10 +54,9 @@ def test_project_full_size_runoff_regime_matches_oracle(product, oracle):
     dt = 1 s; 6 s of GPU time - the oracle would need an hour); its state at the end of that hour - H of every node and the adaptive
     time step - is then handed to BOTH libraries through the state setters (the application's own restart path,
     criteria3DProject.cpp:2934-3123), and both take the first computeStep calls of the dry hour from there, where the time step falls
-    to its minimum and restore-best steps occur: H within 1e-6, identical accepted dt, identical counters.  120 calls by default (the
-    oracle needs ~2 s per call at this size), 300 with SF3D_LONG_TESTS=1."""
-    import os
-    steps = 300 if os.environ.get("SF3D_LONG_TESTS") == "1" else 120
+    to its minimum and restore-best steps occur: H within 1e-6, identical accepted dt, identical counters.  300 calls (the oracle
+    needs ~1 s per call at this size on 16 threads)."""
+    steps = 300
     m = ravone_project_model(None)
     assert m.ns == 422282 and m.n > 5_000_000
     product.check(product.lib.sf3d_reset_solver_state(), "reset")
