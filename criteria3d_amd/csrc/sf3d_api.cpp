@@ -121,11 +121,146 @@ double nodePsi(uint32_t i)                                          /* :140-158 
     return (1. / s.alpha) * std::pow(temp, 1. / s.n);
 }
 
+/* ---- multi-GPU: strip-local device models --------------------------------------------------------------------------------------
+ * The caller builds the same GLOBAL model on every rank (the API is global: a drop-in keeps its caller).  What goes to the device of
+ * rank r is only what its rows touch: the nodes it owns plus the one-cell halo, renumbered 0..n-1 in global order (surface nodes
+ * first, layer-major: the numbering the kernels rely on survives, and so do the chunk-uniform link offsets inside a layer), links
+ * remapped, owners and halo lists handed over in local indices (HostModel::presetPartition).  Device memory and upload time per rank
+ * are then ~1/world of the global model's (+ halo) instead of all of it.  M stays the staging copy the setters and getters see; L
+ * is what the solver sees; dirty parts go M -> L before every device call, fetched fields come back L -> M for the local nodes
+ * (halo included: the device's halo values are as current as its last exchange, exactly what the global-index path keeps).
+ * SF3D_DIST_LOCAL=0 keeps the global-index path of rounds 1-2 (every rank uploads the whole model): the checker of this one. */
+struct LocalModel {
+    bool on = false;                 /* decided at sf3d_dist_prepare */
+    bool built = false;
+    HostModel L;
+    std::vector<uint32_t> l2g;
+    std::vector<int32_t> g2l;
+    Partition part;                  /* local indices */
+};
+LocalModel LM;
+int distRank = 0, distWorld = 1;
+
+template <class T> void gatherTo(std::vector<T>& dst, const std::vector<T>& src)
+{
+    dst.resize(LM.l2g.size());
+    if (src.size() < M.N) { std::fill(dst.begin(), dst.end(), T()); return; }
+    for (size_t k = 0; k < LM.l2g.size(); ++k) dst[k] = src[LM.l2g[k]];
+}
+template <class T> void scatterFrom(std::vector<T>& dst, const std::vector<T>& src)
+{
+    if (dst.size() < M.N || src.size() < LM.l2g.size()) return;
+    for (size_t k = 0; k < LM.l2g.size(); ++k) dst[LM.l2g[k]] = src[k];
+}
+
+/* (re)build L from M: the rank's nodes, links remapped, partition in local indices */
+sf3d_error_t buildLocal()
+{
+    Partition gp;
+    sf3d_error_t e = sf3d_compute_partition(M, distRank, distWorld, gp);
+    if (e != SF3D_OK) return e;
+    std::vector<uint8_t> in(M.N, 0);
+    for (uint32_t i = 0; i < M.N; ++i) if (gp.owner[i] == distRank) in[i] = 1;
+    for (int p = 0; p < distWorld; ++p) for (uint32_t i : gp.recv[p]) in[i] = 1;
+    LM.l2g.clear(); LM.g2l.assign(M.N, -1);
+    for (uint32_t i = 0; i < M.N; ++i) if (in[i]) { LM.g2l[i] = (int32_t)LM.l2g.size(); LM.l2g.push_back(i); }
+    HostModel& L = LM.L;
+    L = HostModel();
+    L.initialized = M.initialized; L.solverReady = M.solverReady; L.water = M.water; L.heat = M.heat; L.solutes = M.solutes;
+    L.cgArrays = M.cgArrays; L.compat = M.compat; L.heatVapor = M.heatVapor; L.heatAdvection = M.heatAdvection; L.heatSave = M.heatSave;
+    L.N = (uint32_t)LM.l2g.size();
+    L.ns = 0; for (uint32_t g : LM.l2g) if (g < M.ns) ++L.ns;
+    L.globalN = M.N;
+    gatherTo(L.x, M.x); gatherTo(L.y, M.y); gatherTo(L.z, M.z); gatherTo(L.size, M.size); gatherTo(L.surf, M.surf);
+    gatherTo(L.hasClass, M.hasClass); gatherTo(L.cls, M.cls); gatherTo(L.btype, M.btype); gatherTo(L.bslope, M.bslope); gatherTo(L.bsize, M.bsize);
+    gatherTo(L.bflowRate, M.bflowRate); gatherTo(L.bflowSum, M.bflowSum); gatherTo(L.prescribed, M.prescribed); gatherTo(L.nLat, M.nLat);
+    for (int s = 0; s < SF3D_SLOTS; ++s) {
+        gatherTo(L.ltype[s], M.ltype[s]); gatherTo(L.lto[s], M.lto[s]); gatherTo(L.larea[s], M.larea[s]); gatherTo(L.lflowSum[s], M.lflowSum[s]);
+        for (uint32_t k = 0; k < L.N; ++k) {
+            if (L.ltype[s][k] == SF3D_LINK_NONE) { L.lto[s][k] = 0; continue; }
+            const int32_t t = LM.g2l[L.lto[s][k]];
+            if (t < 0) { L.ltype[s][k] = SF3D_LINK_NONE; L.lto[s][k] = 0; }      /* a halo node's link out of the local set: its row is never computed */
+            else L.lto[s][k] = (uint32_t)t;
+        }
+    }
+    gatherTo(L.Se, M.Se); gatherTo(L.K, M.K); gatherTo(L.H, M.H); gatherTo(L.sink, M.sink); gatherTo(L.pond, M.pond);
+    L.soils = M.soils; L.roughness = M.roughness;
+    if (M.heat) {
+        gatherTo(L.temperature, M.temperature); gatherTo(L.heatSink, M.heatSink);
+        gatherTo(L.bHeightWind, M.bHeightWind); gatherTo(L.bHeightT, M.bHeightT); gatherTo(L.bRoughH, M.bRoughH); gatherTo(L.bT, M.bT); gatherTo(L.bRH, M.bRH);
+        gatherTo(L.bWind, M.bWind); gatherTo(L.bNetIrr, M.bNetIrr); gatherTo(L.bFixT, M.bFixT); gatherTo(L.bFixDepth, M.bFixDepth);
+        gatherTo(L.bAero, M.bAero); gatherTo(L.bSoilCond, M.bSoilCond); gatherTo(L.bSens, M.bSens); gatherTo(L.bLat, M.bLat); gatherTo(L.bRad, M.bRad); gatherTo(L.bAdv, M.bAdv);
+    }
+    /* the partition in local indices (lists stay sorted: the local numbering is monotonic in the global one, so both ends of an
+     * exchange still enumerate its nodes in the same order) */
+    Partition& lp = LM.part;
+    lp = Partition(); lp.world = distWorld; lp.rank = distRank; lp.bounds = gp.bounds;
+    lp.owner.resize(L.N);
+    for (uint32_t k = 0; k < L.N; ++k) lp.owner[k] = gp.owner[LM.l2g[k]];
+    lp.send.assign(distWorld, {}); lp.recv.assign(distWorld, {});
+    for (int p = 0; p < distWorld; ++p) {
+        for (uint32_t g : gp.send[p]) lp.send[p].push_back((uint32_t)LM.g2l[g]);
+        for (uint32_t g : gp.recv[p]) lp.recv[p].push_back((uint32_t)LM.g2l[g]);
+    }
+    L.presetPartition = &LM.part;
+    /* everything is new to the device */
+    L.graphDirty = L.stateDirty = L.sinkDirty = L.pondDirty = L.boundaryDirty = L.flowSumsDirty = L.ctrlDirty = true;
+    L.sinkLo = 0; L.sinkHi = UINT32_MAX;
+    L.heatStateDirty = L.heatSinkDirty = L.heatBoundaryDirty = true;
+    M.graphDirty = M.stateDirty = M.sinkDirty = M.pondDirty = M.boundaryDirty = M.flowSumsDirty = M.ctrlDirty = false;
+    M.heatStateDirty = M.heatSinkDirty = M.heatBoundaryDirty = false;
+    M.hostStaleState = M.hostStaleFlows = M.hostStaleHeat = false;
+    LM.built = true;
+    return SF3D_OK;
+}
+
+bool needState(); bool needFlows(); bool needHeatState();
+/* the model the device works on, brought up to date with what the setters changed in M since the last call */
+HostModel& deviceModel()
+{
+    if (!LM.on) return M;
+    if (!LM.built || M.graphDirty) {
+        if (LM.built && dev().ready()) {                         /* a re-built topology: what the device knows better goes back to M first, */
+            needState(); needFlows(); if (M.heat) needHeatState();
+            dev().release();                                     /* then windows, arrays and graphs go, like a re-initialisation */
+        }
+        if (buildLocal() != SF3D_OK) fprintf(stderr, "sf3d: strip-local model: partition failed\n");
+        return LM.L;
+    }
+    HostModel& L = LM.L;
+    if (M.stateDirty) { gatherTo(L.H, M.H); gatherTo(L.Se, M.Se); gatherTo(L.K, M.K); L.stateDirty = true; L.hostStaleState = false; M.stateDirty = false; }
+    if (M.sinkDirty) { gatherTo(L.sink, M.sink); L.sinkDirty = true; L.sinkLo = 0; L.sinkHi = UINT32_MAX; M.sinkDirty = false; }
+    if (M.pondDirty) { gatherTo(L.pond, M.pond); L.pondDirty = true; M.pondDirty = false; }
+    if (M.boundaryDirty) { gatherTo(L.btype, M.btype); gatherTo(L.bslope, M.bslope); gatherTo(L.bsize, M.bsize); gatherTo(L.prescribed, M.prescribed); L.boundaryDirty = true; M.boundaryDirty = false; }
+    if (M.flowSumsDirty) {
+        gatherTo(L.bflowSum, M.bflowSum);
+        for (int s = 0; s < SF3D_SLOTS; ++s) gatherTo(L.lflowSum[s], M.lflowSum[s]);
+        L.flowSumsDirty = true; L.hostStaleFlows = false; M.flowSumsDirty = false;
+    }
+    if (M.ctrlDirty) { L.ctrlDirty = true; M.ctrlDirty = false; }
+    if (M.heat) {
+        if (M.heatStateDirty) { gatherTo(L.temperature, M.temperature); L.heatStateDirty = true; L.hostStaleHeat = false; M.heatStateDirty = false; }
+        if (M.heatSinkDirty) { gatherTo(L.heatSink, M.heatSink); L.heatSinkDirty = true; M.heatSinkDirty = false; }
+        if (M.heatBoundaryDirty) {
+            gatherTo(L.bHeightWind, M.bHeightWind); gatherTo(L.bHeightT, M.bHeightT); gatherTo(L.bRoughH, M.bRoughH); gatherTo(L.bT, M.bT); gatherTo(L.bRH, M.bRH);
+            gatherTo(L.bWind, M.bWind); gatherTo(L.bNetIrr, M.bNetIrr); gatherTo(L.bFixT, M.bFixT); gatherTo(L.bFixDepth, M.bFixDepth);
+            L.heatBoundaryDirty = true; M.heatBoundaryDirty = false;
+        }
+    }
+    return L;
+}
+/* is the host copy of a field older than the device's? (asked of the model the device works on) */
+bool staleState() { return LM.on ? (LM.built && LM.L.hostStaleState) : M.hostStaleState; }
+bool staleFlows() { return LM.on ? (LM.built && LM.L.hostStaleFlows) : M.hostStaleFlows; }
+bool staleHeat() { return LM.on ? (LM.built && LM.L.hostStaleHeat) : M.hostStaleHeat; }
+
 /* make the host copy of a field current before it is read or partially overwritten */
 bool needState()
 {
-    if (M.hostStaleState && dev().ready()) {
-        if (dev().fetch_state(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+    if (staleState() && dev().ready()) {
+        HostModel& D = LM.on ? LM.L : M;
+        if (dev().fetch_state(D) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+        if (LM.on) { scatterFrom(M.H, D.H); scatterFrom(M.Se, D.Se); scatterFrom(M.K, D.K); }
         /* surface conventions of the setters (soilFluxes3D.cpp:819-820, 880-881) */
         for (uint32_t i = 0; i < M.ns; ++i) { M.Se[i] = 1.; }
     }
@@ -133,13 +268,18 @@ bool needState()
 }
 bool needFlows()
 {
-    if (M.hostStaleFlows && dev().ready())
-        if (dev().fetch_flows(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+    if (staleFlows() && dev().ready()) {
+        HostModel& D = LM.on ? LM.L : M;
+        if (dev().fetch_flows(D) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+        if (LM.on) {
+            scatterFrom(M.bflowSum, D.bflowSum); scatterFrom(M.bflowRate, D.bflowRate);
+            for (int s = 0; s < SF3D_SLOTS; ++s) scatterFrom(M.lflowSum[s], D.lflowSum[s]);
+        }
+    }
     return true;
 }
 
 template <class T> void reset(std::vector<T>& v, size_t n) { v.assign(n, T()); }
-bool needHeatState();
 
 #define NEED_INIT_E   if (!M.initialized) return SF3D_MEMORY_ERROR
 #define NEED_NODE_E(i) if ((i) >= M.N) return SF3D_INDEX_ERROR
@@ -157,6 +297,7 @@ sf3d_error_t sf3d_clean(void)                                       /* soilFluxe
     if (!M.initialized) return SF3D_OK;
     dev().release();
     M = HostModel();
+    LM.built = false; LM.L = HostModel(); LM.l2g.clear(); LM.g2l.clear();       /* (LM.on stays: sf3d_dist_prepare comes before sf3d_initialize) */
     return SF3D_OK;
 }
 
@@ -195,7 +336,7 @@ sf3d_error_t sf3d_initialize_balance(void)                          /* soilFluxe
 {
     if (!M.initialized) return SF3D_MEMORY_ERROR;
     double wc = 0.;
-    sf3d_error_t e = dev().total_water_content(M, P, &wc);
+    sf3d_error_t e = dev().total_water_content(deviceModel(), P, &wc);
     if (e != SF3D_OK) { fprintf(stderr, "sf3d: initializeBalance: %s\n", dev().last_error()); return e; }
     Ctrl& c = dev().ctrl();
     wholePeriod.storage = curPeriod.storage = wc;
@@ -210,7 +351,7 @@ sf3d_error_t sf3d_initialize_balance(void)                          /* soilFluxe
     M.flowSumsDirty = true;
     if (M.heat) {                                                   /* initializeHeatBalance, heat.cpp:31-53 */
         double hs = 0.;
-        e = dev().heat_storage(M, P, &hs);
+        e = dev().heat_storage(deviceModel(), P, &hs);
         if (e != SF3D_OK) { fprintf(stderr, "sf3d: initializeBalance (heat): %s\n", dev().last_error()); return e; }
         Ctrl& ch = dev().ctrl();
         heatWholePeriod = HeatBal(); heatCurPeriod = HeatBal();
@@ -368,7 +509,7 @@ sf3d_error_t sf3d_set_node_link(uint32_t i, uint32_t j, sf3d_link_t dir, double 
         default: return SF3D_PARAMETER_ERROR;
     }
     M.ltype[s][i] = dir; M.lto[s][i] = j; M.larea[s][i] = area;
-    if (M.water) { if (M.hostStaleFlows) needFlows(); M.lflowSum[s][i] = 0.; M.flowSumsDirty = true; }
+    if (M.water) { needFlows(); M.lflowSum[s][i] = 0.; M.flowSumsDirty = true; }
     M.graphDirty = true;
     return SF3D_OK;
 }
@@ -506,7 +647,7 @@ double sf3d_get_total_water_content(void)                           /* soilFluxe
 {
     if (!M.initialized) return -1;
     double wc = 0.;
-    if (dev().total_water_content(M, P, &wc) != SF3D_OK) { fprintf(stderr, "sf3d: getTotalWaterContent: %s\n", dev().last_error()); return std::nan(""); }
+    if (dev().total_water_content(deviceModel(), P, &wc) != SF3D_OK) { fprintf(stderr, "sf3d: getTotalWaterContent: %s\n", dev().last_error()); return std::nan(""); }
     return wc;
 }
 double sf3d_get_water_storage(void) { return dev().ctrl().curStep.storage; }
@@ -518,8 +659,14 @@ double sf3d_get_water_mbr(void) { return wholePeriod.MBR; }
 #define HEAT_OFF_D if (!M.heat) return errValue(SF3D_MISSING_DATA_ERROR)
 static bool needHeat()
 {
-    if (M.hostStaleHeat && dev().ready())
-        if (dev().fetch_heat(M) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+    if (staleHeat() && dev().ready()) {
+        HostModel& D = LM.on ? LM.L : M;
+        if (dev().fetch_heat(D) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return false; }
+        if (LM.on) {
+            scatterFrom(M.temperature, D.temperature); scatterFrom(M.bAero, D.bAero); scatterFrom(M.bSoilCond, D.bSoilCond);
+            scatterFrom(M.bSens, D.bSens); scatterFrom(M.bLat, D.bLat); scatterFrom(M.bRad, D.bRad); scatterFrom(M.bAdv, D.bAdv);
+        }
+    }
     return true;
 }
 namespace { bool needHeatState() { return needHeat(); } }
@@ -548,7 +695,12 @@ double sf3d_get_node_temperature(uint32_t i)
 static double heatQuery(int what, uint32_t i, double h)
 {
     double out = std::nan("");
-    if (dev().heat_query(M, P, what, i, h, &out) != SF3D_OK) fprintf(stderr, "sf3d: heat query failed: %s\n", dev().last_error());
+    HostModel& D = deviceModel();
+    if (LM.on) {                       /* node index in the strip-local numbering; only nodes of this rank's strip can be asked */
+        if (i >= LM.g2l.size() || LM.g2l[i] < 0) { fprintf(stderr, "sf3d: heat query: node %u is not on this rank\n", i); return out; }
+        i = (uint32_t)LM.g2l[i];
+    }
+    if (dev().heat_query(D, P, what, i, h, &out) != SF3D_OK) fprintf(stderr, "sf3d: heat query failed: %s\n", dev().last_error());
     return out;
 }
 double sf3d_get_node_heat_conductivity(uint32_t i)
@@ -562,6 +714,15 @@ static double linkHeatFlux(int slot, uint32_t i, sf3d_flux_t t)                 
     if (!M.heat) return SF3D_NODATA;
     if (M.heatSave == 1) { if (t != 0) return SF3D_NODATA; }
     else if (M.heatSave != 2 || t >= SF3D_FLUX_TYPES) return SF3D_NODATA;
+    if (LM.on) {
+        HostModel& D = deviceModel();
+        if (i >= LM.g2l.size() || LM.g2l[i] < 0) return SF3D_NODATA;                       /* not on this rank */
+        if (!D.lfluxValid[t]) {
+            if (!dev().ready()) return (M.ltype[slot][i] != SF3D_LINK_NONE) ? SF3D_NODATA : 0.;
+            if (dev().fetch_link_flux(D, t) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return std::nan(""); }
+        }
+        return D.lfluxCache[t][(size_t)slot * D.N + (uint32_t)LM.g2l[i]];
+    }
     if (!M.lfluxValid[t]) {
         if (!dev().ready()) return (M.ltype[slot][i] != SF3D_LINK_NONE) ? SF3D_NODATA : 0.;   /* setNodeLink initialisation */
         if (dev().fetch_link_flux(M, t) != SF3D_OK) { fprintf(stderr, "sf3d: %s\n", dev().last_error()); return std::nan(""); }
@@ -601,7 +762,7 @@ double sf3d_compute_step(double maxDt)                               /* soilFlux
     if (!M.initialized || !M.solverReady) { fprintf(stderr, "sf3d: computeStep before initializeSF3D\n"); return std::nan(""); }
     if (dev().fatal()) { fprintf(stderr, "sf3d: computeStep refused after a fatal device failure: %s\n", dev().last_error()); return std::nan(""); }
     double dt = std::nan("");
-    sf3d_error_t e = dev().step(M, P, maxDt, &dt);
+    sf3d_error_t e = dev().step(deviceModel(), P, maxDt, &dt);
     if (e != SF3D_OK) {
         /* the reference's computeStep ignores run()'s error code (soilFluxes3D.cpp:1796) and returns the dt of a stepNan attempt;
          * so does this one - after saying so - unless the device itself failed (no dt, peer time-out, heat step not started) */
@@ -730,7 +891,7 @@ sf3d_error_t sf3d_synchronize(void)
 {
     /* push every pending host edit (sinks, ponds, state, parameters) to the device, then drain the stream */
     if (M.initialized && M.solverReady) {
-        sf3d_error_t e = dev().sync_to_device(M, P);
+        sf3d_error_t e = dev().sync_to_device(deviceModel(), P);
         if (e != SF3D_OK) { fprintf(stderr, "sf3d: synchronize: %s\n", dev().last_error()); return e; }
     }
     return dev().synchronize();
@@ -741,12 +902,18 @@ sf3d_error_t sf3d_dist_prepare(int rank, int world)
 {
     sf3d_error_t e = dev().dist_prepare(rank, world);
     if (e != SF3D_OK) fprintf(stderr, "sf3d: %s\n", dev().last_error());
+    else {
+        const char* le = getenv("SF3D_DIST_LOCAL");
+        distRank = rank; distWorld = world;
+        LM.on = world > 1 && !(le && le[0] == '0');      /* strip-local device models (SF3D_DIST_LOCAL=0: every rank uploads the global model) */
+        LM.built = false;
+    }
     return e;
 }
 sf3d_error_t sf3d_dist_export(void* blob)
 {
     if (!M.initialized) return SF3D_MEMORY_ERROR;
-    sf3d_error_t e = dev().dist_export(M, P, static_cast<DistBlob*>(blob));
+    sf3d_error_t e = dev().dist_export(deviceModel(), P, static_cast<DistBlob*>(blob));
     if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_export: %s\n", dev().last_error());
     return e;
 }
@@ -843,6 +1010,7 @@ sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32
     return SF3D_OK;
 }
 
+uint64_t sf3d_device_bytes(void) { return dev().device_bytes(); }
 sf3d_error_t sf3d_kernel_timing(int mode) { return dev().timing(mode); }
 int sf3d_kernel_count(void) { return KID_COUNT; }
 const char* sf3d_kernel_name(int k) { return DeviceSolver::kernel_name(k); }

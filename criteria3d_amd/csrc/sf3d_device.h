@@ -250,6 +250,7 @@ struct PairGrid {
 
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
+    uint32_t Nnorm;                     /* node count the mean norm of a sweep divides by: N, or the global count for a strip-local model */
     uint32_t nChunks;                   /* ceil(N / 64): one wave processes one chunk at a time */
     uint32_t qSplit;                    /* chunks [0, qSplit) hold every surface node (runoff/infiltration rows, generic
                                            assembly kernel); chunks [qSplit, nChunks) are soil-only */

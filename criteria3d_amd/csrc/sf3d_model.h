@@ -31,6 +31,7 @@ struct ParamsHost {                    /* SolverParameters, types.h:291-315 (per
     bool lineal = false;               /* setUseLineal(true) AND SF3D_LINEAL_DEVICE_CG=1: device conjugate gradients instead of Jacobi sweeps */
 };
 
+struct Partition;
 struct HostModel {
     bool initialized = false, solverReady = false;
     bool water = true, heat = false, solutes = false;
@@ -65,6 +66,11 @@ struct HostModel {
     bool ctrlDirty = true;       /* parameters or balances edited on the host                     */
     uint32_t sinkLo = 0, sinkHi = UINT32_MAX;   /* node range [lo, hi) touched since the last sink upload (hourly sinks usually cover the
                                                   * surface nodes only: 2 MB instead of 42 MB at 512 x 512 x 20) */
+    /* multi-GPU, strip-local models (sf3d_api.cpp LocalModel): this model holds only the nodes a rank's rows touch (owned + one-cell
+     * halo) in LOCAL numbering; the partition comes ready-made in local indices and the mean norm of the Jacobi sweep divides by the
+     * GLOBAL node count */
+    const struct Partition* presetPartition = nullptr;
+    uint32_t globalN = 0;                       /* 0: this IS the global model */
     /* what the host lacks (device is newer) */
     bool hostStaleState = false; /* H, Se, K                                                      */
     bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */
@@ -137,6 +143,7 @@ public:
     static const char* kernel_name(int kid);
     sf3d_error_t device_log(uint32_t n, const double* x, double* out, bool exponential = false);   /* test hook: the kernels' log / exp */
     sf3d_error_t device_pow(uint32_t n, const double* x, const double* y, double* out);   /* test hook: the property kernels' pow */
+    uint64_t device_bytes() const;               /* bytes of device memory the model's arrays take (sum of the allocations) */
 
 private:
     DeviceSolver() = default;

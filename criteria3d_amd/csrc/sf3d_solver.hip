@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(SF3D_BLOCK) k_decide_sweep(DevView v)
     if (!dist_allgather(v, c, vals, 0)) return;
     if (v.world > 1) dist_unpack(v, par, 0, v.X[nxt]);     /* neighbours' new iterate on my halo */
     if (threadIdx.x != 0) return;
-    sweep_decision(c, nxt, vals[0] / v.N);
+    sweep_decision(c, nxt, vals[0] / v.Nnorm);
 }
 
 /* computeCurrentMassBalance, water.cpp:96-123 */
@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void body_sweep(const DevView& v)
         if (!dist_allgather(v, v.ctrl, vals, 0)) return;                  /* also the barrier that makes the neighbours' puts visible */
         if (!v.haloDirect) dist_unpack(v, par, DF_X, v.X[nxt]);           /* neighbours' new iterate on my halo */
     }
-    if (threadIdx.x == 0) { v.ctrl->singleLaunches++; sweep_decision(v.ctrl, nxt, vals[0] / v.N); }
+    if (threadIdx.x == 0) { v.ctrl->singleLaunches++; sweep_decision(v.ctrl, nxt, vals[0] / v.Nnorm); }
 }
 template <int MODE, bool NT>
 __global__ void __launch_bounds__(SF3D_BLOCK) k_sweep(DevView v)
@@ -1791,6 +1791,7 @@ sf3d_error_t DeviceSolver::set_device(int dev)
     return SF3D_OK;
 }
 
+static uint64_t g_deviceBytes = 0;          /* bytes behind the current model's allocations (sf3d_device_bytes) */
 sf3d_error_t DeviceSolver::release()
 {
     if (!impl_) return SF3D_OK;
@@ -1804,6 +1805,7 @@ sf3d_error_t DeviceSolver::release()
     I.graphs.clear();
     for (void* p : I.allocs) hipFree(p);
     I.allocs.clear();
+    g_deviceBytes = 0;
     if (I.comm && I.pCommDestroy) { I.pCommDestroy(I.comm); I.comm = nullptr; }
     I.rcclMode = false; I.rcclMine = I.rcclGathered = nullptr;
     for (void* p : I.peerMaps) hipIpcCloseMemHandle(p);
@@ -1830,9 +1832,10 @@ template <class T> static hipError_t dev_alloc(std::vector<void*>& allocs, T*& p
 {
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
-    if (e == hipSuccess) { allocs.push_back(q); p = static_cast<T*>(q); }
+    if (e == hipSuccess) { allocs.push_back(q); p = static_cast<T*>(q); g_deviceBytes += (uint64_t)(count ? count : 1) * sizeof(T); }
     return e;
 }
+uint64_t DeviceSolver::device_bytes() const { return g_deviceBytes; }
 
 static void fill_params(Ctrl& c, const ParamsHost& p)
 {
@@ -1877,7 +1880,7 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
         I.N = N; I.ns = ns;
         DevView& v = I.v;
         v = DevView{};
-        v.N = N; v.ns = ns;
+        v.N = N; v.ns = ns; v.Nnorm = m.globalN ? m.globalN : N;
         v.nChunks = (N + SF3D_CHUNK - 1) / SF3D_CHUNK;
         v.qSplit = (ns + SF3D_CHUNK - 1) / SF3D_CHUNK;
         if (v.qSplit > v.nChunks) v.qSplit = v.nChunks;
@@ -2185,8 +2188,11 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
 
         /* ownership + chunk lists (identity lists on one GPU) */
         {
-            sf3d_error_t pe = sf3d_compute_partition(m, rank_, world_, I.part);
-            if (pe != SF3D_OK) { snprintf(err_, sizeof(err_), "partition failed"); return pe; }
+            if (m.presetPartition) I.part = *m.presetPartition;      /* strip-local model: owners and halo lists in local indices */
+            else {
+                sf3d_error_t pe = sf3d_compute_partition(m, rank_, world_, I.part);
+                if (pe != SF3D_OK) { snprintf(err_, sizeof(err_), "partition failed"); return pe; }
+            }
         }
         std::vector<uint32_t> listSurf, listSoil;
         for (uint32_t q = 0; q < nChunks; ++q) {
@@ -2722,7 +2728,7 @@ sf3d_error_t DeviceSolver::dist_export(HostModel& m, const ParamsHost& p, DistBl
     sf3d_error_t e = sync_to_device(m, p);
     if (e != SF3D_OK) return e;
     std::memset(out, 0, sizeof(*out));
-    out->world = world_; out->rank = rank_; out->nodes = m.N;
+    out->world = world_; out->rank = rank_; out->nodes = m.globalN ? m.globalN : m.N;
     if (world_ == 1) return SF3D_OK;
     Impl& I = *impl_;
     hipIpcMemHandle_t h;
@@ -2754,7 +2760,7 @@ sf3d_error_t DeviceSolver::dist_connect(const DistBlob* all)
     char why[200] = {0};                  /* why the window exchange is not usable on this rank (empty: it is) */
     for (int r = 0; r < world_; ++r) {
         const DistBlob& b = all[r];
-        if ((int)b.world != world_ || (int)b.rank != r || b.nodes != I.N) { snprintf(err_, sizeof(err_), "dist_connect: blob %d does not match (world %u rank %u nodes %llu)", r, b.world, b.rank, (unsigned long long)b.nodes); return SF3D_PARAMETER_ERROR; }
+        if ((int)b.world != world_ || (int)b.rank != r || b.nodes != all[rank_].nodes) { snprintf(err_, sizeof(err_), "dist_connect: blob %d does not match (world %u rank %u nodes %llu)", r, b.world, b.rank, (unsigned long long)b.nodes); return SF3D_PARAMETER_ERROR; }
         if (r == rank_) continue;
         /* both sides derived the lists from the same global graph: counts must agree */
         if (b.recvCount[rank_] != d.sendCount[r]) { snprintf(err_, sizeof(err_), "dist_connect: rank %d expects %u nodes from me, I send %u", r, b.recvCount[rank_], d.sendCount[r]); return SF3D_TOPOGRAPHY_ERROR; }

@@ -362,12 +362,15 @@ sf3d_error_t sf3d_device_exp(uint32_t count, const double* x, double* out);
 sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out);
 
 /* ---- multi-GPU: one process per GPU, row strips of surface-cell columns ------
- * Every rank builds the SAME global model through the setters above; the library computes only the
- * strip it owns and exchanges one-cell halos with its neighbours device-to-device (HIP-IPC windows
+ * Every rank builds the SAME global model through the setters above; the library uploads and computes only
+ * the strip it owns (+ one-cell halo, renumbered locally) and exchanges halos with its neighbours device-to-device (HIP-IPC windows
  * over xGMI, device-side flags).  Call order: sf3d_dist_prepare(rank, world) -> sf3d_initialize ...
  * graph / state setters ... -> sf3d_dist_export(blob) -> [the launcher all-gathers the blobs, e.g.
  * torch.distributed / MPI] -> sf3d_dist_connect(all blobs) -> sf3d_initialize_balance -> steps.
  * Getters answer for the nodes a rank owns (sf3d_dist_owner); scalar balances are global. */
+/* bytes of device memory behind the model's arrays on this rank (0 for libraries without a device); with strip-local device models
+ * (default for world > 1; SF3D_DIST_LOCAL=0: every rank uploads the whole global model) about 1 / world of the single-rank figure + halo */
+uint64_t     sf3d_device_bytes(void);
 int          sf3d_dist_blob_bytes(void);
 sf3d_error_t sf3d_dist_prepare(int rank, int world);
 sf3d_error_t sf3d_dist_export(void* blob_out);

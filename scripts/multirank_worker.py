@@ -64,6 +64,7 @@ for h, item in enumerate(plan):
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
         res[f"{k}_h{h}"] = np.array(s[k])
 res["seconds"] = np.array(time.time() - t0)
+res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
 np.savez(outfile, **res)

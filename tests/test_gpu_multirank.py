@@ -16,13 +16,15 @@ ROOT = Path(__file__).resolve().parent.parent
 RTOL = 1e-6
 
 
-def run_ranks(world, case, tmp_path, port):
+def run_ranks(world, case, tmp_path, port, env=None):
+    import os
     procs, outs = [], []
     for r in range(world):
-        out = tmp_path / f"rank{r}.npz"
+        out = tmp_path / f"rank{r}_{port}.npz"
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), str(world),
-                                       str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                       str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                      env=dict(os.environ, **(env or {}))))
     logs = []
     for p in procs:
         try:
@@ -84,6 +86,33 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
             tot = sum(float(res[f"{k}_h{h}"]) for res in ranks)
             assert abs(tot - snap[k]) <= RTOL * max(abs(snap[k]), 1e-3), (k, tot, snap[k])
     assert all((res["counters"] == ranks[0]["counters"]).all() for res in ranks)
+    if case == "c4f20h0":
+        # strip-local device models: a rank holds its 64 rows + one halo row on either side of 512, not the whole grid
+        product = capi.load_product()
+        product.check(product.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(product, m)
+        whole = int(product.lib.sf3d_device_bytes())
+        product.lib.sf3d_clean()
+        per_rank = [int(res["device_bytes"]) for res in ranks]
+        assert whole > 3e9 and max(per_rank) < 0.2 * whole, (whole, per_rank)
+
+
+@pytest.mark.parametrize("world,case,port", [(3, "c2f60", 29641), (2, "ragged", 29643), (3, "random", 29645)])
+def test_strip_local_models_equal_the_global_index_path(tmp_path, world, case, port):
+    """the default for world > 1 - every rank uploads only its strip + halo, renumbered locally - against the checker mode
+    SF3D_DIST_LOCAL=0 (every rank uploads the whole global model, indices global): the same bits on every owned node, the same
+    accepted steps and counters; and less device memory"""
+    local = run_ranks(world, case, tmp_path, port)
+    glob = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_DIST_LOCAL": "0"})
+    owner = glob[0]["owner"]
+    for r in range(world):
+        mine = owner == r
+        for k in local[r].files:
+            if k.startswith(("H_h", "Se_h")):
+                assert np.array_equal(local[r][k][mine], glob[r][k][mine]), (r, k)
+            elif k.startswith(("dts_h", "storage_h", "total_water_h", "runoff_h", "drainage_h", "lateral_h")) or k == "counters":
+                assert np.array_equal(local[r][k], glob[r][k]), (r, k)
+        assert int(local[r]["device_bytes"]) < int(glob[r]["device_bytes"])
 
 
 @pytest.mark.parametrize("world,port", [(3, 29622)])
