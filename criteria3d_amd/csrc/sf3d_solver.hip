@@ -1982,7 +1982,8 @@ sf3d_error_t DeviceSolver::sync_to_device(HostModel& m, const ParamsHost& p)
                         dist[e] = m.z[su] - m.z[so];
                     }
                 }
-                if (m.btype[i] == SF3D_BND_FREE_DRAINAGE && m.ltype[0][i] == SF3D_LINK_NONE) bad = true;   /* assert water.cpp:682 */
+                if (m.btype[i] == SF3D_BND_FREE_DRAINAGE && m.ltype[0][i] == SF3D_LINK_NONE
+                    && (m.presetPartition == nullptr || m.presetPartition->owner[i] == rank_)) bad = true;   /* assert water.cpp:682 (a strip-local model's halo nodes may have lost the link: their rows and boundaries are the neighbour's) */
             }
         });
         if (bad) { snprintf(err_, sizeof(err_), "FreeDrainage node without an Up link"); return SF3D_BOUNDARY_ERROR; }

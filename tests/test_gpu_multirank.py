@@ -100,8 +100,8 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
 @pytest.mark.parametrize("world,case,port", [(3, "c2f60", 29641), (2, "ragged", 29643), (3, "random", 29645)])
 def test_strip_local_models_equal_the_global_index_path(tmp_path, world, case, port):
     """the default for world > 1 - every rank uploads only its strip + halo, renumbered locally - against the checker mode
-    SF3D_DIST_LOCAL=0 (every rank uploads the whole global model, indices global): the same bits on every owned node, the same
-    accepted steps and counters; and less device memory"""
+    SF3D_DIST_LOCAL=0 (every rank uploads the whole global model, indices global): the same bits in H and Se of every owned node,
+    the same accepted steps and counters, the balance sums equal to rounding; and less device memory"""
     local = run_ranks(world, case, tmp_path, port)
     glob = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_DIST_LOCAL": "0"})
     owner = glob[0]["owner"]
@@ -110,8 +110,12 @@ def test_strip_local_models_equal_the_global_index_path(tmp_path, world, case, p
         for k in local[r].files:
             if k.startswith(("H_h", "Se_h")):
                 assert np.array_equal(local[r][k][mine], glob[r][k][mine]), (r, k)
-            elif k.startswith(("dts_h", "storage_h", "total_water_h", "runoff_h", "drainage_h", "lateral_h")) or k == "counters":
+            elif k.startswith("dts_h") or k == "counters":
                 assert np.array_equal(local[r][k], glob[r][k]), (r, k)
+            elif k.startswith(("storage_h", "total_water_h", "runoff_h", "drainage_h", "lateral_h")):
+                # sums over the rank's nodes: the local numbering groups the nodes into other blocks, so the same terms are added in
+                # another association (identical on regular grids, last bits on irregular ones)
+                np.testing.assert_allclose(local[r][k], glob[r][k], rtol=1e-12, atol=1e-300)
         assert int(local[r]["device_bytes"]) < int(glob[r]["device_bytes"])
 
 
