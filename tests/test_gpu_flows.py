@@ -142,6 +142,26 @@ def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 
+def test_c4_f60_hour0_matches_oracle(product, oracle):
+    """the runoff-regime workload of the bench line (`f60_hour0`: C4 512x512x20 under 60 mm in hour 0): 76 accepted
+    steps with 42 Courant rejections - every accepted dt, every counter, H, Se and the balances after the hour"""
+    m = cm.catchment_model(512, 512, 20)
+    res = []
+    for sf in (product, oracle):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=16)
+        _, d = cm.run_hour(sf, m, 60.0)
+        res.append((d, cm.snapshot(sf, m), sf.counters()))
+    (gd, gs, gc), (od, os_, oc) = res
+    assert len(gd) == len(od) == 76
+    np.testing.assert_allclose(gd, od, rtol=1e-12)
+    _snap_close(gs, os_, "C4 F60 h0")
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    assert gc["courant_rejections"] == 42
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
 def test_c4_f20_all_six_hours_match_oracle(product, oracle):
     """the workload the headline is quoted on (C4 512x512x20, F20, 6 simulated hours): H, Se, storage and boundary sums after
     every hour, identical accepted-dt sequences and work counters"""
