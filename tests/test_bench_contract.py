@@ -106,6 +106,24 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_falls_back_to_labelled_replicas():
+    """a node on which the strips cannot be connected (forced here) still gives a line: N independent replicas, `scaling` weak,
+    the reason in `config.partition`, `value` = N x the hours each replica simulated over the slowest replica's time"""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SF3D_BENCH_SHARE_GPU"] = "1"; env["SF3D_BENCH_FORCE_REPLICAS"] = "1"
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "0", "--reps", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "INDEPENDENT REPLICAS" in line["config"]["partition"]
+    assert abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+    assert line["config"]["work"]["accepted"] == 22 + 13
+
+
+@pytest.mark.gpu
 def test_bench_rank_without_a_gpu_stops_the_run():
     """two ranks asked for on a box with one GPU (and no SF3D_BENCH_SHARE_GPU): rank 1 has no device of its own and says so; the
     parent stops rank 0 instead of leaving it waiting in a collective, and returns the failing rank's code"""
