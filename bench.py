@@ -146,7 +146,22 @@ def spawn_ranks(n, argv):
     sys.exit(worst)
 
 
-def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0, threads=32):
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), None without a limit: OpenMP threads beyond it
+    are throttled, not run (measured on this pool: quota 16 of 256 logical CPUs - 16 threads 0.52 s per oracle step, 32 threads 0.64)"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20.0, threads=0):
     """Reference CPU/OpenMP path on a bounded sample: computeStep calls from the same initial
     state until `budget_s` seconds of CPU work are spent (at least one step)."""
     from tests import checkers          # checker libraries (oracle/): this leg only
@@ -164,7 +179,10 @@ def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(threads, avail))
+    quota = cpu_quota()
+    if quota is not None:
+        avail = max(1, min(avail, int(quota + 0.5)))
+    cores = max(1, min(threads if threads > 0 else 32, avail))
     if kind == "port":
         sf.lib.sf3d_reset_solver_state()
     t_build = time.perf_counter()
@@ -187,6 +205,7 @@ def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20
     if gpu_steps and nsteps >= 1 and len(gpu_steps[1]) >= nsteps:
         gpu_wall = gpu_steps[1][nsteps - 1][0] - gpu_steps[0]      # end of step nsteps - start of hour 0
     out = {"value": (sim / 3600.0) / wall if wall > 0 else None, "unit": "sim-h/s", "cores": cores, "kind": kind,
+           "host_cpu_quota": quota, "host_logical_cpus": os.cpu_count(),
            "sample": f"first {nsteps} computeStep calls ({sim:.0f} simulated s of hour 0) of {workload_name} {forcing}, "
                      f"{wall:.1f} s wall"}
     if gpu_wall:
@@ -209,7 +228,7 @@ def main():
     ap.add_argument("--time-all-kernels", action="store_true", help="HIP-event timing of every node kernel (adds ~5%% overhead)")
     ap.add_argument("--reps", type=int, default=0, help="repetitions of the timed region, each from the initial state (rewound, not rebuilt); the median is reported; 0 = at least 3 and as many as it takes to time 1.5 s (at most 15)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--cpu-threads", type=int, default=32, help="OpenMP threads of the CPU baseline (best measured: 16-32)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline; 0 = min(32, CPUs the container may use: affinity and cgroup quota)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

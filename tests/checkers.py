@@ -20,6 +20,17 @@ def load_oracle() -> SF3D:
     return SF3D(ORACLE_LIB)
 
 
+def load_oracle_copy(tag: str) -> SF3D:
+    """A second, independent instance of the oracle in this process (the library keeps its model in globals): the file is copied
+    under another name, so the loader maps it again with globals of its own.  For tests that let two oracle runs go side by side."""
+    import shutil
+    import tempfile
+    d = Path(tempfile.mkdtemp(prefix="sf3d_oracle_"))
+    f = d / f"libsf3d_oracle_{tag}.so"
+    shutil.copy(ORACLE_LIB, f)
+    return SF3D(f)
+
+
 def _reference(name: str) -> SF3D:
     if QT_CORE.exists():
         C.CDLL(str(QT_CORE), mode=C.RTLD_GLOBAL)   # linked by soname, deliberately not on the rpath
