@@ -244,7 +244,7 @@ struct PairGrid {
     /* layered MASKED grids (k_sweep_pair_masked: DEM outlines, soil columns of different depth): NX x NY x NZ is the bounding grid */
     uint32_t masked;                    /* 1: the fields below describe the graph, chunkCode is unused */
     const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
-    const uint32_t* patchList;          /* [blocks] non-empty patches: (patch row << 12) | patch column */
+    const uint32_t* patchList;          /* [blocks] patches that hold nodes: (band of W - 2 rows << 12) | first column (NX <= 4096; else column / 64) */
     const uint8_t* patchDepth;          /* [blocks] layers the patch (halo included) reaches */
 };
 
