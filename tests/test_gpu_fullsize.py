@@ -177,7 +177,7 @@ def test_paired_sweep_on_awkward_grids(product, shape, w):
     assert ca == cb
 
 
-@pytest.mark.parametrize("which,w", [("dem_window", "10"), ("project_window", "6"), ("random_holes", "14"), ("random_holes_wide", "10")])
+@pytest.mark.parametrize("which,w", [("dem_window", "10"), ("project_window", "6"), ("random_holes", "14"), ("random_holes_wide", "10"), ("full_box", "10")])
 def test_paired_sweep_on_masked_grids(product, which, w):
     """k_sweep_pair_masked against k_sweep on layered MASKED grids - DEM outlines with holes, soil columns that end at different depths,
     a random subset of the lateral links, both row orientations: same H, Se, accepted steps and counters, bit for bit"""
@@ -189,12 +189,14 @@ def test_paired_sweep_on_masked_grids(product, which, w):
         m = ravone_project_model((980, 1060, 330, 420))
     elif which == "random_holes":
         m = cm.random_model(23, nx=70, ny=45, nz=5)
+    elif which == "full_box":          # a regular grid sent through the masked kernel (SF3D_PAIR_FORCE_MASKED: the measurement switch)
+        m = cm.catchment_model(128, 48, 8, heterogeneous=True)
     else:
         m = cm.random_model(5, nx=150, ny=20, nz=4)
     assert m.ns >= 64
     res = []
     for pair in ("0", "1"):
-        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w, SF3D_PAIR_FORCE_MASKED="1" if which == "full_box" else "0"):
             product.check(product.lib.sf3d_reset_solver_state(), "reset")
             cm.build(product, m)
             product.check(product.lib.sf3d_kernel_timing(1), "timing")       # event statistics tell which sweep kernel ran
