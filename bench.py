@@ -469,8 +469,9 @@ def main():
         paired = stats.get("k_sweep_pair", (0,))[0] > 0
         n_rank = model.n // split
         b_j = 80 if paired else 152
-        step_bytes = n_rank * (b_j * work["sweeps"] + B_APPROX * work["approximations"] + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
-        survey_bytes = n_rank * (152 * work["sweeps"] + B_APPROX * work["approximations"] + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
+        n_a = work["approximations"] - work.get("early_courant_rejections", 0)      # (an attempt the early Courant check refused moved next to nothing)
+        step_bytes = n_rank * (b_j * work["sweeps"] + B_APPROX * n_a + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
+        survey_bytes = n_rank * (152 * work["sweeps"] + B_APPROX * n_a + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
         roofline["step"] = {"bytes": step_bytes, "elapsed_s": elapsed, "achieved": step_bytes / elapsed / 1e9, "unit": "GB/s",
                             "frac": step_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
                             "model": f"N ({b_j} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R) per rank, counters of the timed region"

@@ -156,7 +156,7 @@ SIGNATURES = {
 REFERENCE_API = [k for k in SIGNATURES if k != "sf3d_backend_name"][:70]
 
 COUNTER_NAMES = ["attempts", "accepted", "approximations", "sweeps", "courant_rejections",
-                 "linear_failures", "restores", "reserved"]
+                 "linear_failures", "restores", "early_courant_rejections"]
 
 
 BOUNDARY_HEAT_FIELDS = ("height_wind", "height_temperature", "roughness", "temperature", "relative_humidity",

@@ -860,7 +860,7 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
 {
     const Ctrl& c = dev().ctrl();
     for (int k = 0; k < 8; ++k) out[k] = dev().ready() ? c.counters[k] : 0;
-    out[7] = 0;
+    out[7] = dev().ready() ? c.earlyCourant : 0;      /* (slot 7 of the device block counts balance decisions: internal) */
     return SF3D_OK;
 }
 double sf3d_get_linear_residual(void) { return dev().ready() ? dev().ctrl().lastNorm : -9999.; }

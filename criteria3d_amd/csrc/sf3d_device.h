@@ -152,6 +152,7 @@ struct Ctrl {
     uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */
     uint32_t compatSeq;       /* last assembly mirrored                                                            */
     uint32_t compatPad;
+    uint64_t earlyCourant;    /* attempts the early Courant check (k_courant_probe) refused before the full properties + assembly ran: a subset of counters[4] */
     /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
     uint64_t counters[8];
 };
@@ -255,6 +256,7 @@ struct DevView {
     uint32_t qSplit;                    /* chunks [0, qSplit) hold every surface node (runoff/infiltration rows, generic
                                            assembly kernel); chunks [qSplit, nChunks) are soil-only */
     uint32_t nbSurf, nbSoil;            /* grid sizes of the two assembly kernels */
+    double probeMin;                    /* early Courant check (k_courant_probe) runs while the last Courant number is at least this; < 0: never */
     /* chunks this rank computes (all chunks when world == 1): whole list, its surface part
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;

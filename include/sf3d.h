@@ -308,8 +308,10 @@ sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint3
 /* Work counters since sf3d_initialize (the same events SURVEY.md App. B instruments in
  * cpusolver.cpp): out[0] attempts (waterMainLoop iterations), [1] accepted steps,
  * [2] approximations, [3] Jacobi sweeps, [4] Courant rejections, [5] linear-solver failures,
- * [6] restore-best calls, [7] reserved.  The "reference" backend cannot count (unmodified
- * sources) and returns SF3D_MISSING_DATA_ERROR. */
+ * [6] restore-best calls, [7] those of [4] that the HIP product's early Courant check decided before the full
+ * approximation ran (an implementation detail of the product, 0 in the CPU libraries: the early check changes no
+ * result and no other counter).  The "reference" backend cannot count (unmodified sources) and returns
+ * SF3D_MISSING_DATA_ERROR. */
 sf3d_error_t sf3d_get_counters(uint64_t out[8]);
 
 /* Stopping quantity of the LAST linear solve of the water system: Jacobi - the mean scaled update of the last sweep

@@ -66,7 +66,7 @@ for h, item in enumerate(plan):
 res["seconds"] = np.array(time.time() - t0)
 res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 c = sf.counters()
-res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
+res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
 np.savez(outfile, **res)
 dist.barrier()
 sf.lib.sf3d_clean()

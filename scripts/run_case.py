@@ -30,6 +30,7 @@ res["lateral_out"] = np.array([sf.lib.sf3d_get_node_sum_lateral_water_flow_out(i
 res["down"] = np.array([sf.lib.sf3d_get_node_max_water_flow(int(i), capi.LINK_DOWN) for i in range(0, m.n, max(1, m.n // 4096))])
 res["boundary"] = sf.boundary_water_flow(0, m.n)
 c = sf.counters()
-res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES], dtype=np.int64)
+res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
+res["early_courant"] = np.array(c["early_courant_rejections"], dtype=np.int64)      # how the product got there: not compared between modes
 np.savez(out, **res)
 sf.lib.sf3d_clean()
