@@ -83,7 +83,8 @@ def _launch_modes(full):
              dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_OVERLAP_ACCEPT="0")]
     if full:
         modes += [fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"),
-                  dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0")]
+                  dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0"),
+                  dict(base, SF3D_COURANT_PROBE="always")]
     return modes
 
 
