@@ -280,6 +280,9 @@ struct DevView {
     const double *bslope, *bsize, *prescribed;
     const uint32_t* lto;                /* [10][N] */
     const uint8_t* lkind;               /* [10][N] */
+    const uint8_t* probeMask;           /* [ns] early Courant check: bit s - 2 set = lateral slot s of the surface node is the end that evaluates its
+                                         * runoff link (the Courant term of a link is bit-identical from both ends: the one with the larger
+                                         * neighbour index evaluates it, or the only one where the link has no reverse) */
     const double *larea, *ldist;        /* [10][N] interface area (read only where a chunk's areas differ) and link distance */
     double* lflowSum;                   /* [10][N] */
     sf3d_d2* A2x[2];                    /* two copies of [5][N] row-normalised off-diagonals, slots paired (2p, 2p+1): 16-byte accesses.  The

@@ -200,3 +200,36 @@ def test_reinitialise_and_clean_cycles(product, oracle):
         assert product.lib.sf3d_clean() == capi.OK
         assert product.lib.sf3d_clean() == capi.OK          # idempotent (cpp:220-221)
         assert product.lib.sf3d_get_node_total_potential(0) == -2222.0
+
+
+@pytest.mark.parametrize("one_way", [False, True])
+def test_early_courant_check_takes_the_same_decisions(product, oracle, one_way):
+    """The early Courant check (k_props_surface + k_courant_probe) evaluates every runoff link from ONE of its ends and refuses an
+    attempt before the full approximation is computed - forced on before every approximation here: the same accepted steps, the same
+    counters and the same state as the oracle under the 60 mm hour (Courant rejections), also where a third of the lateral surface
+    links exist in one direction only (the end that has the link must then be the one that evaluates it)."""
+    import dataclasses
+    from tests.scenarios import env
+    m = cm.catchment_model(48, 40, 5)
+    if one_way:
+        rng = np.random.RandomState(3)
+        lateral_surface = (m.link_dir == capi.LINK_LATERAL) & (m.link_node < m.ns)
+        drop = lateral_surface & (rng.rand(m.link_node.size) < 0.33) & ((m.link_node > m.link_to) == (rng.rand(m.link_node.size) < 0.5))
+        keep = ~drop
+        m = dataclasses.replace(m, link_node=m.link_node[keep], link_to=m.link_to[keep], link_dir=m.link_dir[keep], link_area=m.link_area[keep])
+    with env(SF3D_COURANT_PROBE="always"):
+        for sf in (product, oracle):
+            sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(sf, m, threads=8)
+    # (with one-way links the system loses its symmetry and the run crawls at the minimum dt after its first 100 steps: 150 are taken)
+    for mm, mx in (((60.0, 150),) if one_way else ((60.0, None), (0.0, 40))):
+        _, gd = cm.run_hour(product, m, mm, max_steps=mx)
+        _, od = cm.run_hour(oracle, m, mm, max_steps=mx)
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-9
+    gc, oc = product.counters(), oracle.counters()
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    assert gc["courant_rejections"] >= (5 if one_way else 30) and gc["early_courant_rejections"] == gc["courant_rejections"], gc
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
