@@ -14,3 +14,10 @@ mkdir -p $ROOT/build_variants
 cd $ROOT
 SF3D_PRODUCT_LIB=$ROOT/build_variants/libasan_host.so LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   python -m pytest tests/test_abi.py tests/test_api_fuzz.py tests/test_regular_grid.py tests/test_partition_gloo.py -x -q -m "not gpu" -p no:cacheprovider
+# the checker itself: the oracle built with gcc's ASan + UBSan against its golden vectors, the call-sequence fuzz and the project model
+# (about six minutes); the regular build is put back afterwards
+cp $ROOT/oracle/libsf3d_oracle.so /tmp/libsf3d_oracle_keep.so
+trap 'cp /tmp/libsf3d_oracle_keep.so $ROOT/oracle/libsf3d_oracle.so' EXIT
+g++ -std=c++17 -O1 -g -fopenmp -ffp-contract=off -fPIC -shared -fsanitize=address,undefined -I$ROOT/include -o $ROOT/oracle/libsf3d_oracle.so $ROOT/oracle/sf3d_oracle.cpp
+LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+  python -m pytest tests/test_oracle_golden.py tests/test_api_fuzz.py tests/test_project3d.py -x -q -m "not gpu and not slow" -p no:cacheprovider
