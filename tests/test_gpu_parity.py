@@ -233,3 +233,34 @@ def test_early_courant_check_takes_the_same_decisions(product, oracle, one_way):
         assert gc[k] == oc[k], (k, gc, oc)
     assert gc["courant_rejections"] >= (5 if one_way else 30) and gc["early_courant_rejections"] == gc["courant_rejections"], gc
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 21)))
+def test_random_irregular_models_with_every_fast_path_forced(product, oracle, seed):
+    """Fuzz over graph shapes: random holes, column depths, layer thicknesses, soils, boundary types and a random subset of the lateral
+    links (catchment.random_model), with the fast paths a small grid would not get by itself forced on - the masked paired sweep and the
+    early Courant check before every approximation - against the oracle: accepted dt, counters, H and Se after a 30 mm burst and a dry
+    stretch."""
+    from tests.scenarios import env
+    rng = np.random.RandomState(100 + seed)
+    m = cm.random_model(seed, nx=int(rng.randint(66, 90)), ny=int(rng.randint(8, 30)), nz=int(rng.randint(3, 7)))
+    assert m.ns >= 64
+    with env(SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_COURANT_PROBE="always"):
+        for sf in (product, oracle):
+            sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(sf, m, threads=4)
+    product.check(product.lib.sf3d_kernel_timing(1), "timing")
+    for mm, mx in ((30.0, 60), (0.0, 40)):
+        _, gd = cm.run_hour(product, m, mm, max_steps=mx)
+        _, od = cm.run_hour(oracle, m, mm, max_steps=mx)
+        np.testing.assert_allclose(gd, od, rtol=1e-12)
+    stats = product.kernel_stats()
+    product.lib.sf3d_kernel_timing(0)
+    assert stats["k_sweep_pair"][0] > 0, stats          # the masked paired sweep really ran
+    g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
+    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-8
+    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-7
+    gc, oc = product.counters(), oracle.counters()
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
