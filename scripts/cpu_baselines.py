@@ -43,6 +43,25 @@ def main():
     ncpu = os.cpu_count() or 1
     res = {"host_threads": ncpu, "cpu_model": next((l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"), "runs": []}
     quick = len(sys.argv) > 2 and sys.argv[2] == "tuned"     # only the -O3 -march=x86-64-v3 build next to the project-flags build
+    if len(sys.argv) > 2 and sys.argv[2] == "quota":
+        # round 3: the GPU boxes give a container 16 CPUs' worth of time (cgroup cpu.max) of their 256 logical CPUs - thread counts around
+        # that quota, both builds, and the runoff-regime sample (C4 F60 hour 0, as far as 25 s go)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            res["cgroup_cpu_quota"] = None if q == "max" else float(q) / float(per)
+        except (OSError, ValueError):
+            res["cgroup_cpu_quota"] = None
+        for backend in ("reference", "reference_tuned"):
+            for threads in (1, 8, 16):
+                res["runs"].append(run(backend, (64, 64, 10), "F20", 6, threads))
+            res["runs"].append(run(backend, (256, 256, 15), "F20", 2, 16, budget=40.0))
+            for threads in (8, 16, 32):
+                res["runs"].append(run(backend, (512, 512, 20), "F20", 1, threads, budget=25.0))
+            res["runs"].append(run(backend, (512, 512, 20), "F60", 1, 16, budget=25.0))
+        json.dump(res, open(out, "w"), indent=1)
+        for r in res["runs"]:
+            print(r)
+        return
     for backend in (("reference", "reference_tuned") if quick else ("reference",)):
         for threads in ((1, 16) if quick else (1, 16, 64, ncpu)):
             res["runs"].append(run(backend, (64, 64, 10), "F20", 6, threads))
