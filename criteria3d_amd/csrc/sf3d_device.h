@@ -152,6 +152,10 @@ struct Ctrl {
     uint32_t asmSurfOnly;     /* 1: the Courant check refused the attempt - the reference had assembled only the surface rows by then */
     uint32_t compatSeq;       /* last assembly mirrored                                                            */
     uint32_t compatPad;
+    uint32_t probeBudget;     /* early Courant check: approximations it still runs for - refilled by every Courant refusal, used up by checks that pass
+                               * (a run whose Courant number sits just below 1 without ever being refused - a real catchment at its Courant-limited
+                               * dt - would otherwise pay the check before every approximation for nothing) */
+    uint32_t probePad;
     uint64_t earlyCourant;    /* attempts the early Courant check (k_courant_probe) refused before the full properties + assembly ran: a subset of counters[4] */
     /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
     uint64_t counters[8];
