@@ -137,13 +137,23 @@ def ravone_window(sf, threads=1):
 RAVONE_PROJECT_WINDOW = (1000, 1048, 352, 400)
 
 
+_PROJECT_MODELS = {}
+
+
 def ravone_project_model(window=RAVONE_PROJECT_WINDOW):
     """BASELINE config 5 as specified, cut to a window: DEM + soil map + soil database + land use of DATA/PROJECT/Ravone
-    (tests/golden/ravone_project.npz) through criteria3d_amd.project3d.project_model"""
+    (tests/golden/ravone_project.npz) through criteria3d_amd.project3d.project_model.  The whole project (window None: 19 s of
+    host work, 5.85 M nodes) is built once per process and handed out again - callers do not modify a model."""
     from pathlib import Path
     from criteria3d_amd import project3d as p3
+    key = tuple(window) if window is not None else None
+    if key in _PROJECT_MODELS:
+        return _PROJECT_MODELS[key]
     inp = p3.load_project_fixture(Path(__file__).resolve().parent / "golden" / "ravone_project.npz")
-    return p3.project_model(p3.window(inp, *window) if window is not None else inp)
+    m = p3.project_model(p3.window(inp, *window) if window is not None else inp)
+    if window is None:
+        _PROJECT_MODELS[key] = m
+    return m
 
 
 def ravone_project_window(sf, threads=1):
