@@ -446,6 +446,15 @@ def main():
                     run_traffic = prof["whole_run"]["hbm_traffic_GB"] * 1e9
                 traffic_source = f"stored profile profiles/{f.name} (rocprofv3 --pmc passes of this command; not measured in this run)"
             break
+        if traffic is None and world == 1 and args.workload == "C5" and not args.heat and dom:
+            # the Ravone project: PMC passes of `bench.py --workload C5 --steps 1` (the paired sweep runs as k_sweep_pair_masked there)
+            f5 = ROOT / "profiles" / "r03_b_C5_pmc_traffic.json"
+            if f5.exists() and not (os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")):
+                p5 = json.load(open(f5))
+                k5 = "k_sweep_pair_masked" if dom == "k_sweep_pair" else dom
+                if k5 in p5 and "hbm_traffic_MB" in p5[k5]:
+                    traffic = p5[k5]["hbm_traffic_MB"] * 1e6
+                    traffic_source = f"stored profile profiles/{f5.name} (rocprofv3 --pmc passes of --workload C5 --steps 1; not measured in this run)"
     except Exception:  # noqa: BLE001
         pass
     if dom and stats[dom][0] > 0:
