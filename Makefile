@@ -12,7 +12,8 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off
 all: product shim
 
 product: $(CSRC)/libsf3d_hip.so
-$(CSRC)/libsf3d_hip.so: $(CSRC)/sf3d_solver.hip $(CSRC)/sf3d_heat.inc $(CSRC)/sf3d_pair.inc $(CSRC)/sf3d_cg.inc $(CSRC)/sf3d_pair_masked.inc $(CSRC)/sf3d_fastmath.inc $(CSRC)/sf3d_fastmath_tables.h $(CSRC)/sf3d_api.cpp $(CSRC)/sf3d_device.h $(CSRC)/sf3d_model.h include/sf3d.h
+# every part of the translation unit (the .inc files hold nearly all kernel and host code) and every header is a prerequisite
+$(CSRC)/libsf3d_hip.so: $(CSRC)/sf3d_solver.hip $(CSRC)/sf3d_api.cpp $(wildcard $(CSRC)/*.inc $(CSRC)/*.h) include/sf3d.h
 	$(HIPCC) $(HIPFLAGS) -Iinclude -I$(CSRC) -x hip $(CSRC)/sf3d_solver.hip $(CSRC)/sf3d_api.cpp -o $@
 
 shim: shim/libsoilFluxes3D_mi355x.so

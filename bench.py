@@ -15,8 +15,7 @@ over ranks is reported.  `value` = K simulated hours / that time.
 
 The timed region is repeated (default: at least 3 times and until 1.5 s have been timed, at most 15; --reps fixes the count), each time from
 the initial state - rewound through the API, not rebuilt, so that the repetitions keep the GPU busy back to back - and the MEDIAN elapsed time
-is reported (`value`, `ms_per_step`; all repetitions in `repeats_s`).  `headline_6h` is the same measurement restricted to the
-timed hours 0-5 - the 6-hour figure SURVEY.md 8d quotes - whenever K >= 6, so that it is driver-timed whatever K is.
+is reported (all repetitions in `repeats_s`).  `headline_6h` repeats `value` with its elapsed time (kept for readers of earlier rounds' lines).
 `inclusive_value` puts the hourly sink/source upload (host -> HBM) inside the clock; it is never `value`.
 `python bench.py --gpus N` without a launcher spawns its own N ranks (fresh child processes, before anything touches the
 GPU) and relays rank 0's line.
@@ -59,12 +58,21 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, heat=None, per_hour=None, inclusive=None):
+EPISODE_HOURS = 6           # "C4: F20 6 sim-h for the headline number"
+
+
+def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, heat=None, per_hour=None, inclusive=None, rewind=None,
+              counters_at=None):
     """Run `hours` simulated hours; return wall seconds spent inside the computeStep loops.
     per_hour: list receiving each hour's seconds; inclusive: one-element list accumulating the seconds with the hourly input
-    upload (sink/source array, atmosphere) inside the clock."""
+    upload (sink/source array, atmosphere) inside the clock.  rewind: called (outside the clock) after every EPISODE_HOURS hours - the
+    timed region walks through the 6-hour episode again from the initial state.  counters_at: list receiving the work counters
+    after every hour (read outside the clock)."""
     total = 0.0
-    for h in range(hours):
+    for k in range(hours):
+        h = k % EPISODE_HOURS if rewind is not None else k
+        if rewind is not None and k > 0 and h == 0:
+            rewind()
         mm = cm.FORCINGS[forcing](h)
         ti = time.perf_counter()
         sf.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(mm, model.cell_area)))
@@ -89,6 +97,8 @@ def run_hours(sf, cm, model, forcing, hours, per_step=None, hour_starts=None, he
             per_hour.append(t1 - t0)
         if inclusive is not None:
             inclusive[0] += t1 - ti
+        if counters_at is not None:
+            counters_at.append(sf.counters())
     return total
 
 
@@ -330,11 +340,13 @@ def main():
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
 
     t0 = time.perf_counter()
-    replicas = None            # set to the reason when the strips could not be connected on this node
+    replicas = None            # set to the reason when the strips could not be connected on this node AND replicas were allowed
     if world > 1:
-        # the strip exchange (HIP-IPC windows between the ranks' GPUs) has only ever run with the ranks sharing one GPU:
-        # a node on which it cannot be set up gets N independent replicas of the workload - labelled as such on the line - rather
-        # than no line.  Every rank takes the same decision (the failures this covers come after the hand-over of the handles).
+        # The strip exchange (HIP-IPC windows between the ranks' GPUs) is the metric's multi-GPU path.  If it cannot be set up the run
+        # FAILS (exit 4, the reasons of every rank on stderr): N independent copies of the workload are not the metric.  Only with
+        # SF3D_BENCH_ALLOW_REPLICAS=1 does the run go on as N replicas - `value` is then ONE replica's rate (never multiplied by N),
+        # the aggregate goes under `replica_throughput`, and the line says so in `config.partition` and `scaling`.
+        os.environ.setdefault("SF3D_DIST_VERBOSE", "1")      # every rank reports on stderr which exchange came up (bus ids, peer access, window self-check)
         why = ""
         try:
             if os.environ.get("SF3D_BENCH_FORCE_REPLICAS") == "1":
@@ -342,10 +354,19 @@ def main():
             fresh()
         except Exception as e:  # noqa: BLE001
             why = f"rank {rank}: {e}"
-        whys = [w for w in allgather_bytes(why.encode()) if w]
+        whys = [w.decode() for w in allgather_bytes(why.encode()) if w]
         if whys:
-            replicas = whys[0].decode()[:300]
-            log(f"[bench] rank {rank}: strips not connected ({replicas}); running {world} independent replicas instead")
+            for w in whys:
+                log(f"[bench] strips not connected - {w[:400]}")
+            if os.environ.get("SF3D_BENCH_ALLOW_REPLICAS") != "1":
+                log(f"[bench] rank {rank}: the multi-GPU exchange could not be set up; no line is printed "
+                    "(SF3D_BENCH_ALLOW_REPLICAS=1 runs labelled independent replicas instead)")
+                sf.lib.sf3d_clean()
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(4)
+            replicas = whys[0][:300]
+            log(f"[bench] rank {rank}: SF3D_BENCH_ALLOW_REPLICAS=1: running {world} independent replicas instead")
             sf.lib.sf3d_clean()
             sf.lib.sf3d_dist_prepare(0, 1)
             shard = None
@@ -362,18 +383,19 @@ def main():
     # instruments every node kernel of every step (eager launches, ~6 % slower)
     sf.check(sf.lib.sf3d_kernel_timing(0 if args.no_kernel_timing else (1 if args.time_all_kernels else 2)), "kernel_timing")
     reps = max(1, args.reps) if args.reps > 0 else 3          # --reps 0: at least 3, and as many as it takes to time >= 1.5 s (<= 15)
-    rep_elapsed, rep_hours, rep_incl = [], [], []
+    rep_elapsed, rep_incl, rep_episodes, episode_work = [], [], [], None      # (rep_episodes: every complete 6-hour episode of every repetition)
     per_step, hour_starts, c0, work0 = [], [], None, None
     rep = 0
     while rep < reps:
         if rep > 0:
             sf.check(sf.lib.sf3d_kernel_timing(0), "kernel_timing")      # event statistics come from the first repetition only
             rewind()
-        ps, hs_, ph, incl = [], [], [], [0.0]
+        ps, hs_, ph, incl, cat = [], [], [], [0.0], []
         barrier()
         torch.cuda.synchronize()
         cb = sf.counters()
-        el = run_hours(sf, cm, model, args.forcing, args.steps, per_step=ps, hour_starts=hs_, heat=heat, per_hour=ph, inclusive=incl)
+        el = run_hours(sf, cm, model, args.forcing, args.steps, per_step=ps, hour_starts=hs_, heat=heat, per_hour=ph, inclusive=incl,
+                       rewind=rewind, counters_at=cat)
         torch.cuda.synchronize()
         ca = sf.counters()
         did = {k: ca[k] - cb[k] for k in ca}
@@ -381,22 +403,26 @@ def main():
             c0, c1, work0 = cb, ca, did
             stats = sf.kernel_stats()
             per_step, hour_starts = ps, hs_
+            # work of ONE episode (hours 0-5): the counters after hour 5 minus those at the start
+            episode_work = ({k: cat[EPISODE_HOURS - 1][k] - cb[k] for k in cb} if args.steps >= EPISODE_HOURS else None)
         elif {k: x for k, x in did.items() if k != "early_courant_rejections"} != {k: x for k, x in work0.items() if k != "early_courant_rejections"}:
             # (how many Courant refusals the early check took depends on the Courant number the step before left behind - the rewind keeps it)
             raise RuntimeError(f"rank {rank}: repetition {rep} did other work than the first one ({did} vs {work0}): the rewind is not a fresh start")
-        vals = [el, incl[0], sum(ph[:6])] + ph
+        episodes = [sum(ph[e * EPISODE_HOURS:(e + 1) * EPISODE_HOURS]) for e in range(args.steps // EPISODE_HOURS)]
+        vals = [el, incl[0]] + episodes + ph
         if world > 1:
             dist.barrier()
             t = torch.tensor(vals, dtype=torch.float64, device="cpu" if share else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             vals = [float(x) for x in t.tolist()]
-        rep_elapsed.append(vals[0]); rep_incl.append(vals[1]); rep_hours.append(vals[2])
+        rep_elapsed.append(vals[0]); rep_incl.append(vals[1]); rep_episodes.extend(vals[2:2 + len(episodes)])
         if rep == 0 and args.reps <= 0 and vals[0] > 0:          # (the maximum over the ranks: the same decision on every rank)
             reps = int(min(15, max(3, np.ceil(1.5 / vals[0]))))
         rep += 1
     order = sorted(range(reps), key=lambda k: rep_elapsed[k])
     med = order[reps // 2]
-    elapsed, elapsed_incl, elapsed_6h = rep_elapsed[med], rep_incl[med], sorted(rep_hours)[reps // 2]
+    elapsed, elapsed_incl = rep_elapsed[med], rep_incl[med]
+    elapsed_6h = sorted(rep_episodes)[len(rep_episodes) // 2] if rep_episodes else None      # median complete episode
     tw = sf.lib.sf3d_get_total_water_content()
     if not np.isfinite(tw):     # computeStep keeps returning a dt after stepNan, like the reference: such a run measures nothing
         raise RuntimeError(f"rank {rank}: the state is not finite after the timed steps (total water content {tw}): invalid run")
@@ -442,8 +468,8 @@ def main():
             tuned = os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")
             if world == 1 and args.workload == "C4" and not tuned and dom in prof and "hbm_traffic_MB" in prof[dom]:
                 traffic = prof[dom]["hbm_traffic_MB"] * 1e6
-                if args.steps == prof.get("whole_run", {}).get("steps") and args.forcing == "F20":
-                    run_traffic = prof["whole_run"]["hbm_traffic_GB"] * 1e9
+                if args.steps >= EPISODE_HOURS and prof.get("whole_run", {}).get("steps") == EPISODE_HOURS and args.forcing == "F20":
+                    run_traffic = prof["whole_run"]["hbm_traffic_GB"] * 1e9      # counted traffic of one 6-hour episode
                 traffic_source = f"stored profile profiles/{f.name} (rocprofv3 --pmc passes of this command; not measured in this run)"
             break
         if traffic is None and world == 1 and args.workload == "C5" and not args.heat and dom:
@@ -459,7 +485,7 @@ def main():
         pass
     if dom and stats[dom][0] > 0:
         launches, ms, nodes = stats[dom]
-        nodes = nodes // split                    # each rank sweeps its own strip
+        # (sf3d_kernel_stats reports the nodes THIS rank owns - its strip without the halo - so nothing is divided here)
         avg_s = ms / 1e3 / launches
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         note = None
@@ -473,21 +499,23 @@ def main():
                     "note": note,
                     "equivalent_sweep_frac": (EQUIVALENT_SWEEP_BYTES[dom] * nodes / avg_s / 1e9 / HBM_PEAK_GBS) if dom in EQUIVALENT_SWEEP_BYTES else None,
                     "kernels": {k: {"launches": v[0], "total_ms": v[1],
-                                    "GBps": (ALGO_BYTES[k] * (v[2] // split) * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 and k in ALGO_BYTES else None}
+                                    "GBps": (ALGO_BYTES[k] * v[2] * v[0] / (v[1] / 1e3) / 1e9) if v[1] > 0 and k in ALGO_BYTES else None}
                                 for k, v in stats.items()}}
-        # whole timed region (SURVEY 8d's model with the work counters of the run) over the median elapsed time
+        # SURVEY 8d's model with the work counters of one 6-hour episode over the median episode time (K < 6: the whole timed region)
         paired = stats.get("k_sweep_pair", (0,))[0] > 0
         n_rank = model.n // split
         b_j = 80 if paired else 152
-        n_a = work["approximations"] - work.get("early_courant_rejections", 0)      # (an attempt the early Courant check refused moved next to nothing)
-        step_bytes = n_rank * (b_j * work["sweeps"] + B_APPROX * n_a + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
-        survey_bytes = n_rank * (152 * work["sweeps"] + B_APPROX * n_a + B_STEP * work["accepted"] + B_RESTORE * work["restores"])
-        roofline["step"] = {"bytes": step_bytes, "elapsed_s": elapsed, "achieved": step_bytes / elapsed / 1e9, "unit": "GB/s",
-                            "frac": step_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
-                            "model": f"N ({b_j} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R) per rank, counters of the timed region"
+        w_, el_, what = (episode_work, elapsed_6h, "one 6-hour episode (hours 0-5)") if episode_work and elapsed_6h else (work, elapsed, f"the {args.steps} timed hours")
+        n_a = w_["approximations"] - w_.get("early_courant_rejections", 0)      # (an attempt the early Courant check refused moved next to nothing)
+        step_bytes = n_rank * (b_j * w_["sweeps"] + B_APPROX * n_a + B_STEP * w_["accepted"] + B_RESTORE * w_["restores"])
+        survey_bytes = n_rank * (152 * w_["sweeps"] + B_APPROX * n_a + B_STEP * w_["accepted"] + B_RESTORE * w_["restores"])
+        roofline["step"] = {"bytes": step_bytes, "elapsed_s": el_, "achieved": step_bytes / el_ / 1e9, "unit": "GB/s",
+                            "frac": step_bytes / el_ / 1e9 / HBM_PEAK_GBS, "region": what, "work": w_,
+                            "model": f"N ({b_j} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R) per rank, counters of {what}"
                                      + (" (a Jacobi iteration inside a paired pass costs 80 B/node)" if paired else ""),
-                            "survey_8d_bytes": survey_bytes, "survey_8d_frac": survey_bytes / elapsed / 1e9 / HBM_PEAK_GBS,
-                            "traffic": run_traffic, "traffic_frac": (run_traffic / elapsed / 1e9 / HBM_PEAK_GBS) if run_traffic else None}
+                            "survey_8d_bytes": survey_bytes, "survey_8d_frac": survey_bytes / el_ / 1e9 / HBM_PEAK_GBS,
+                            "traffic": run_traffic if w_ is episode_work else None,
+                            "traffic_frac": (run_traffic / el_ / 1e9 / HBM_PEAK_GBS) if (run_traffic and w_ is episode_work) else None}
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not args.heat:      # the baseline leg drives the water-only set-up
         try:
@@ -501,24 +529,29 @@ def main():
 
     line = {
         "metric": "simulated-hours/sec on 512x512x20 grid" if args.workload == "C4" else f"simulated-hours/sec on {nx}x{ny}x{nz} grid",
-        "value": args.steps * (world // split) / elapsed,          # replicas: every rank simulated args.steps hours
+        # the 8d headline: 6 simulated hours over the median complete episode, whatever K is; K < 6: K hours over their time.
+        # (replicas, SF3D_BENCH_ALLOW_REPLICAS=1 only: ONE replica's rate - never multiplied by the number of ranks)
+        "value": (EPISODE_HOURS / elapsed_6h) if elapsed_6h else args.steps / elapsed,
         "unit": "sim-h/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": (elapsed_6h / EPISODE_HOURS if elapsed_6h else elapsed / args.steps) * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if split == world else "weak",
+        "scaling": "strong" if split == world else "weak",      # strong: one fixed grid cut into N strips; weak only for labelled replicas
+        "replica_throughput": (world * ((EPISODE_HOURS / elapsed_6h) if elapsed_6h else args.steps / elapsed)) if replicas is not None else None,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone project (DATA/PROJECT/Ravone: DEM, soil map, soil_ER_2021.db, land use; 13 soil layers to 0.95 m)", "C5DEM": "Ravone DEM with synthetic soils (round-2 stand-in)"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
-                               f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)",
+                               (f"the 6-hour episode from the initial state; {args.steps} timed hours = {args.steps // EPISODE_HOURS} complete episode(s)" + (f" + {args.steps % EPISODE_HOURS} more hour(s)" if args.steps % EPISODE_HOURS else "") + f" per repetition, {reps} repetitions, `value` = 6 h / median episode" if elapsed_6h else f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)"),
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else (f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI" if replicas is None else f"{world} INDEPENDENT REPLICAS of the workload (the strip exchange could not be set up on this node: {replicas})"),
                    "work": work},
         "repeats_s": rep_elapsed,
-        "headline_6h": ({"value": 6.0 / elapsed_6h, "unit": "sim-h/s", "hours": "timed hours 0-5 (SURVEY.md 8d headline workload)",
-                         "elapsed_s": elapsed_6h} if args.steps >= 6 and elapsed_6h > 0 else None),
+        "headline_6h": ({"value": EPISODE_HOURS / elapsed_6h, "unit": "sim-h/s", "hours": "one complete episode, hours 0-5 (SURVEY.md 8d headline workload) = `value`",
+                         "elapsed_s": elapsed_6h, "episodes_s": rep_episodes} if elapsed_6h else None),
+        "timed_region": {"hours": args.steps, "elapsed_s": elapsed, "hours_per_s": args.steps / elapsed,
+                         "note": "all K timed hours (median repetition): complete episodes plus the first K mod 6 hours of one more"},
         "inclusive_value": args.steps / elapsed_incl if elapsed_incl > 0 else None,
         "value_timing": f"median of {reps} repetitions of the timed region; repetition 0 carries the HIP-event sampling of the dominant kernel "
                         f"(every 8th computeStep launched eagerly), the others replay hipGraphs uninstrumented; repetition 0 took {rep_elapsed[0]:.4f} s",

@@ -40,7 +40,7 @@ def _stale(target: Path, sources) -> bool:
 def build_product(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950: kernels + C ABI -> criteria3d_amd/csrc/libsf3d_hip.so"""
     srcs = [CSRC / "sf3d_solver.hip", CSRC / "sf3d_api.cpp"]
-    deps = srcs + [CSRC / "sf3d_physics.inc", CSRC / "sf3d_control.inc", CSRC / "sf3d_phases.inc", CSRC / "sf3d_host_build.inc", CSRC / "sf3d_host_step.inc", CSRC / "sf3d_heat.inc", CSRC / "sf3d_pair.inc", CSRC / "sf3d_cg.inc", CSRC / "sf3d_pair_masked.inc", CSRC / "sf3d_fastmath.inc", CSRC / "sf3d_fastmath_tables.h", CSRC / "sf3d_device.h", CSRC / "sf3d_model.h", INCLUDE / "sf3d.h"]
+    deps = srcs + sorted(CSRC.glob("*.inc")) + sorted(CSRC.glob("*.h")) + [INCLUDE / "sf3d.h"]      # every part of the translation unit (the Makefile rule uses the same wildcard)
     if force or _stale(PRODUCT_LIB, deps):
         extra = os.environ.get("SF3D_EXTRA_HIPFLAGS", "").split()      # tuning experiments, e.g. -DSF3D_PROPS_WAVES=4
         cmd = [HIPCC, *HIP_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-x", "hip", *map(str, srcs), "-o", str(PRODUCT_LIB)]

@@ -220,11 +220,23 @@ HostModel& deviceModel()
 {
     if (!LM.on) return M;
     if (!LM.built || M.graphDirty) {
-        if (LM.built && dev().ready()) {                         /* a re-built topology: what the device knows better goes back to M first, */
+        if (LM.built && dev().ready() && dev().connected()) {
+            /* the topology changed AFTER sf3d_dist_connect: the windows, the halo lists and the peers' view of this rank belong to the old
+             * graph.  Nothing is torn down behind the launcher's back: the local model is marked stale and the device call that follows
+             * fails with SF3D_TOPOGRAPHY_ERROR (sync_to_device) until a new sf3d_dist_prepare / export / connect / finalize round. */
+            LM.L.graphDirty = true;
+            return LM.L;
+        }
+        if (LM.built && dev().ready()) {                         /* a re-built topology before the ranks are connected: what the device knows better goes back to M first, */
             needState(); needFlows(); if (M.heat) needHeatState();
             dev().release();                                     /* then windows, arrays and graphs go, like a re-initialisation */
         }
-        if (buildLocal() != SF3D_OK) fprintf(stderr, "sf3d: strip-local model: partition failed\n");
+        if (buildLocal() != SF3D_OK) {
+            /* (the partition fails only for a bad rank / world, which sf3d_dist_prepare has refused already) - never hand a half-built
+             * model to the solver: an empty one fails its upload loudly */
+            fprintf(stderr, "sf3d: strip-local model: partition failed\n");
+            LM.L = HostModel(); LM.built = false;
+        }
         return LM.L;
     }
     HostModel& L = LM.L;

@@ -125,6 +125,7 @@ public:
     Ctrl& ctrl() { return mirror_; }
     void push_ctrl() { ctrlEdited_ = true; }
     bool ready() const { return built_; }
+    bool connected() const { return world_ > 1 && connected_; }   /* a multi-rank model whose windows are set up */
     const char* last_error() const { return err_; }
     /* true after a failure that leaves the device state unusable (peer time-out of the multi-GPU exchange, a heat step that
      * did not start, a HIP error): computeStep then refuses to go on instead of stalling once more per call */

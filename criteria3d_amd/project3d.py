@@ -539,6 +539,14 @@ def project_model(inp: ProjectInputs, par: ProjectParameters | None = None) -> M
         cand_to[:, 2 + k] = ipad[L + 1, R + 1 + dr, C + 1 + dc]
         cand_dir[:, 2 + k] = capi.LINK_LATERAL
         cand_area[:, 2 + k] = lat
+    # the `continue` statements of the link section (:1044-1046, :1058-1062) leave the node's loop body: a node whose Up target is
+    # missing gets no link at all, and a node whose next layer is within the soil profile but holds no node there - the surface cell of
+    # a ROAD land unit over a valid soil (setIndexMaps gives roads no soil nodes) - gets no LATERAL links: its neighbours still link to
+    # it, one way.  (The Ravone land-use map holds a single non-road unit: no node of BASELINE config 5 takes either branch.)
+    no_up = (L > 0) & (cand_to[:, 0] < 0)
+    cand_to[no_up, 1:] = -1
+    no_down = (L < nz - 1) & within_next & (ipad[np.minimum(L + 2, nz + 1), R + 1, C + 1] < 0)
+    cand_to[no_down, 2:] = -1
     mask = cand_to >= 0
     idx = np.arange(n, dtype=np.int64)
 

@@ -80,6 +80,11 @@ def test_bench_two_ranks_sharing_the_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["work"]["accepted"] == 22
+    # the roofline of an N > 1 line prices what ONE rank's launch works on: the nodes it owns (C2 in two strips: 20 480 of 40 960), once
+    r = line["roofline"]
+    assert r["kernel"] == "k_sweep" and r["algorithmic_bytes_per_launch"] == 152 * 20480, r
+    assert abs(r["achieved"] - 152 * 20480 / (r["avg_us"] * 1e-6) / 1e9) < 1e-9 * r["achieved"]
+    assert "exchange HIP-IPC windows - windows passed the self-check" in p.stderr and "SAME GPU" in p.stderr      # every rank says which exchange came up
 
 
 @pytest.mark.gpu
@@ -99,27 +104,52 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
     assert len(line["repeats_s"]) == 2 and min(line["repeats_s"]) > 0          # --reps 2: rewound, not rebuilt, and checked to do the same work
-    assert line["headline_6h"]["value"] > 0 and abs(line["headline_6h"]["value"] - line["value"]) < 0.35 * line["value"]
+    assert line["headline_6h"]["value"] == line["value"] and abs(line["value"] * line["ms_per_step"] - 1e3) < 1e-6      # `value` IS the 6-hour episode
+    assert line["timed_region"]["hours"] == 6 and line["roofline"]["step"]["region"].startswith("one 6-hour episode")
     assert 0 < line["inclusive_value"] <= line["value"] * 1.02
     assert line["config"]["work"]["accepted"] == 50          # C2 F20: 22 + 13 + 6 + 3 + 3 + 3
     assert "traffic_source" in line["roofline"]
 
 
 @pytest.mark.gpu
-def test_bench_falls_back_to_labelled_replicas():
-    """a node on which the strips cannot be connected (forced here) still gives a line: N independent replicas, `scaling` weak,
-    the reason in `config.partition`, `value` = N x the hours each replica simulated over the slowest replica's time"""
+def test_bench_value_is_the_six_hour_episode_whatever_steps_is():
+    """the driver runs `--steps 20 --warmup 5`: the timed hours walk through the 6-hour episode of SURVEY 8d again and again (rewound
+    outside the clock), `value` is 6 h over the median COMPLETE episode - the 8d headline - and does not depend on --steps"""
+    import subprocess
+    import sys
+    out = {}
+    for steps, warm in ((20, 5), (6, 1)):
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "C2", "--steps", str(steps), "--warmup", str(warm), "--reps", "3",
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[steps] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    a, b = out[20], out[6]
+    assert a["steps"] == 20 and a["warmup"] == 5 and a["headline_6h"]["value"] == a["value"]
+    assert abs(a["value"] - b["value"]) < 0.03 * b["value"], (a["value"], b["value"])          # within 3 % (run-to-run noise of a small grid)
+    assert len(a["headline_6h"]["episodes_s"]) == 3 * 3 and a["timed_region"]["hours"] == 20
+    assert a["config"]["work"]["accepted"] == 3 * 50 + 22 + 13          # three episodes (22 + 13 + 6 + 3 + 3 + 3) and hours 0, 1 of a fourth
+    assert a["roofline"]["step"]["work"]["accepted"] == 50               # the step roofline describes ONE episode
+
+
+@pytest.mark.gpu
+def test_bench_does_not_turn_a_failed_exchange_into_a_headline():
+    """strips that cannot be connected (forced here) are an ERROR: exit code 4, the reason of every rank on stderr, no JSON line.
+    Only SF3D_BENCH_ALLOW_REPLICAS=1 runs N labelled replicas - and then `value` is ONE replica's rate, never N times it"""
     import os
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SF3D_BENCH_ALLOW_REPLICAS")}
     env["SF3D_BENCH_SHARE_GPU"] = "1"; env["SF3D_BENCH_FORCE_REPLICAS"] = "1"
-    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "0", "--reps", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "2", "--warmup", "0", "--reps", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")] and "strips not connected" in p.stderr
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, SF3D_BENCH_ALLOW_REPLICAS="1"))
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "INDEPENDENT REPLICAS" in line["config"]["partition"]
-    assert abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]
+    assert abs(line["value"] - 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]          # two hours over one replica's time
+    assert abs(line["replica_throughput"] - 2 * line["value"]) < 1e-9 * line["value"]
     assert line["config"]["work"]["accepted"] == 22 + 13
 
 
