@@ -139,6 +139,7 @@ SIGNATURES = {
     "sf3d_kernel_stats": (u8, [i32, p64, pd, p64]),
     "sf3d_device_log": (u8, [u32, pd, pd]),
     "sf3d_device_exp": (u8, [u32, pd, pd]),
+    "sf3d_device_cbrt": (u8, [u32, pd, pd]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),
     "sf3d_device_bytes": (u64, []),
     "sf3d_dist_blob_bytes": (i32, []),

@@ -142,7 +142,7 @@ public:
     sf3d_error_t timing(int mode);               /* 0 off, 1 all node kernels, 2 only the Jacobi sweep */
     sf3d_error_t stats(int kid, uint64_t* launches, double* ms, uint64_t* nodes);
     static const char* kernel_name(int kid);
-    sf3d_error_t device_log(uint32_t n, const double* x, double* out, bool exponential = false);   /* test hook: the kernels' log / exp */
+    sf3d_error_t device_log(uint32_t n, const double* x, double* out, int which = 0);   /* test hook: the kernels' log (0) / exp (1) / cbrt (2) */
     sf3d_error_t device_pow(uint32_t n, const double* x, const double* y, double* out);   /* test hook: the property kernels' pow */
     uint64_t device_bytes() const;               /* bytes of device memory the model's arrays take (sum of the allocations) */
 

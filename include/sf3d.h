@@ -360,6 +360,8 @@ sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint
 sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out);
 /* the same for the exp of the heat kernels */
 sf3d_error_t sf3d_device_exp(uint32_t count, const double* x, double* out);
+/* the same for the cbrt of the runoff links' Manning term (x >= 0) */
+sf3d_error_t sf3d_device_cbrt(uint32_t count, const double* x, double* out);
 /* the same for the pow of the soil-property kernels: out[k] = x[k]^y[k], x >= 0 */
 sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out);
 

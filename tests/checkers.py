@@ -20,6 +20,19 @@ def load_oracle() -> SF3D:
     return SF3D(ORACLE_LIB)
 
 
+ORACLE_FM_LIB = ROOT / "oracle" / "libsf3d_oracle_fm.so"
+
+
+def load_oracle_fastmath() -> SF3D:
+    """The fast-math TWIN of the oracle (oracle/Makefile `oracle-fm`): the same restatement compiled with the PRODUCT's elementary
+    functions (criteria3d_amd/csrc/sf3d_fastmath.inc) instead of the C library's.  NOT a checker of results and never the pin: it
+    tells arithmetic sensitivity of a scenario from a kernel effect (tests/test_gpu_sensitivity.py) and nothing else."""
+    if not ORACLE_FM_LIB.exists():
+        import subprocess
+        subprocess.run(["make", "-C", str(ROOT / "oracle"), "oracle-fm"], check=True, stdout=subprocess.DEVNULL)
+    return SF3D(ORACLE_FM_LIB)
+
+
 def load_oracle_copy(tag: str) -> SF3D:
     """A second, independent instance of the oracle in this process (the library keeps its model in globals): the file is copied
     under another name, so the loader maps it again with globals of its own.  For tests that let two oracle runs go side by side."""

@@ -11,3 +11,5 @@ void fm_pow(const double* x, const double* y, double* out, size_t n) { for (size
 void fm_pow_libm(const double* x, const double* y, double* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = pow(x[i], y[i]); }
 void fm_exp(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = sf3d_fexp(x[i]); }
 void fm_exp_libm(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = exp(x[i]); }
+void fm_cbrt(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = sf3d_fcbrt(x[i]); }
+void fm_cbrt_libm(const double* x, double* y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = cbrt(x[i]); }

@@ -183,3 +183,29 @@ def test_reduced_argument_is_exact_for_every_piece():
             r = Fraction(z) * Fraction(invc[i]) - 1
             assert Fraction(float(r)) == r, (i, hex(u))
             assert abs(r) <= Fraction(1, 128)
+
+
+def test_cbrt_error_against_mpmath_and_agreement_with_libm(fm):
+    """sf3d_fcbrt (Manning's Hs^(2/3) = cbrt(Hs^2) of the runoff links): x^(1/3) through the pow machinery with the exponent as
+    hi + lo - below 0.6 ulp against mpmath (measured 0.504) on the water depths squared the runoff links produce and over the whole
+    range.  glibc's cbrt - the reference's - is a 3-ulp routine (measured 2.85 ulp against mpmath on the same samples), so agreement
+    with it is "within its own error": at most 3 ulps apart"""
+    import mpmath as mp
+    mp.mp.prec = 200
+    rng = np.random.default_rng(11)
+    sets = {"depth^2": np.exp(rng.uniform(-24, 6, 200_000)), "whole range": np.exp(rng.uniform(-700, 700, 200_000)),
+            "cubes": np.arange(1, 2000, dtype=np.float64) ** 3, "edges": np.array([0.0, 1.0, 8.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf])}
+    for name, x in sets.items():
+        a, b = fm("fm_cbrt", x), fm("fm_cbrt_libm", x)
+        ok = np.isfinite(b) & (b != 0)
+        assert np.array_equal(a[~ok], b[~ok]), name
+        d = np.abs(a.view(np.int64) - b.view(np.int64))[ok]
+        assert d.max() <= 3, (name, d.max())
+    assert np.array_equal(fm("fm_cbrt", sets["cubes"]), np.arange(1, 2000, dtype=np.float64))          # exact cubes come out exact
+    worst = 0.0
+    for xv in np.concatenate([sets["depth^2"][:4000], sets["whole range"][:2000]]):
+        t = mp.cbrt(mp.mpf(float(xv)))
+        yv = fm("fm_cbrt", np.array([xv]))[0]
+        worst = max(worst, float(abs(mp.mpf(float(yv)) - t) / mp.mpf(float(np.spacing(float(t))))))
+    assert worst < 0.6, worst
+    assert np.isnan(fm("fm_cbrt", np.array([np.nan]))[0])

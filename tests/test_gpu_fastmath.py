@@ -50,3 +50,14 @@ def test_device_exp_equals_host_build(product, fm):  # noqa: F811
         y = np.empty_like(x)
         product.check(product.lib.sf3d_device_exp(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd)), "device_exp")
         assert np.array_equal(y.view(np.int64), fm("fm_exp", x).view(np.int64)), name
+
+
+def test_device_cbrt_equals_host_build(product, fm):  # noqa: F811
+    """the cbrt of the runoff links' Manning term: device == host build of the same text, bit for bit"""
+    rng = np.random.default_rng(21)
+    for name, x in {"depth^2": np.exp(rng.uniform(-24, 6, 1_000_000)), "whole range": np.exp(rng.uniform(-700, 700, 200_000)),
+                    "edges": np.array([0.0, 1.0, 8.0, 27.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, np.inf])}.items():
+        x = np.ascontiguousarray(x)
+        y = np.empty_like(x)
+        product.check(product.lib.sf3d_device_cbrt(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd)), "device_cbrt")
+        assert np.array_equal(y.view(np.int64), fm("fm_cbrt", x).view(np.int64)), name

@@ -243,3 +243,35 @@ def test_paired_sweep_with_heat_and_with_the_compat_rows(product):
         product.lib.sf3d_clean()
     for k in out[0]:
         assert np.array_equal(out[0][k], out[1][k]), k
+
+
+def test_runoff_link_in_an_up_slot_switches_the_early_courant_check_off(product, oracle):
+    """setNodeLink accepts an Up link between two SURFACE nodes; the assembly treats it as a runoff link and counts its Courant term
+    (water.cpp:308-324), but the early Courant check looks at the lateral slots only - its partial maximum would refuse such an attempt
+    with another dt than checkCourant (cpusolver.cpp:248-281).  With such a link in the graph the check stays off: the run under the
+    60 mm forcing (Courant refusals) matches the oracle step for step whatever SF3D_COURANT_PROBE asks for."""
+    import dataclasses
+    from tests.scenarios import env
+    m0 = cm.catchment_model(64, 64, 6)
+    # every 4th cell of rows 8 .. 40 gets one more runoff link, in its Up slot, to the cell one row down the slope
+    r, c = np.meshgrid(np.arange(8, 40), np.arange(1, 64, 4), indexing="ij")
+    a, b = (r * 64 + c).ravel().astype(np.uint32), ((r - 1) * 64 + c).ravel().astype(np.uint32)
+    m = dataclasses.replace(m0, link_node=np.concatenate([m0.link_node, a]), link_to=np.concatenate([m0.link_to, b]),
+                            link_dir=np.concatenate([m0.link_dir, np.full(a.size, capi.LINK_UP, m0.link_dir.dtype)]),
+                            link_area=np.concatenate([m0.link_area, np.full(a.size, 5.0)]))
+    oracle.lib.sf3d_reset_solver_state()
+    cm.build(oracle, m, threads=4)
+    _, od = cm.run_hour(oracle, m, 60.0, max_steps=150)
+    o = cm.snapshot(oracle, m)
+    assert oracle.counters()["courant_rejections"] >= 1
+    for probe in ("always", "0"):
+        with env(SF3D_COURANT_PROBE=probe):
+            product.check(product.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(product, m)
+            _, gd = cm.run_hour(product, m, 60.0, max_steps=150)
+            g = cm.snapshot(product, m)
+            gc = product.counters()
+        np.testing.assert_allclose(gd, od, rtol=1e-12, err_msg=probe)
+        assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6, probe
+        assert gc["early_courant_rejections"] == 0 and gc["courant_rejections"] == oracle.counters()["courant_rejections"], (probe, gc)
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
