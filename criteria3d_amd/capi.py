@@ -140,6 +140,7 @@ SIGNATURES = {
     "sf3d_device_log": (u8, [u32, pd, pd]),
     "sf3d_device_exp": (u8, [u32, pd, pd]),
     "sf3d_device_cbrt": (u8, [u32, pd, pd]),
+    "sf3d_get_sweep_launches": (u8, [p64, p64]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),
     "sf3d_device_bytes": (u64, []),
     "sf3d_dist_blob_bytes": (i32, []),
@@ -287,6 +288,12 @@ class SF3D:
         if code != OK:
             return None
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def sweep_launches(self):
+        """(single sweeps, paired passes) the product launched since sf3d_initialize"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self.check(self.lib.sf3d_get_sweep_launches(C.byref(a), C.byref(b)), "get_sweep_launches")
+        return int(a.value), int(b.value)
 
     # -- multi-GPU bootstrap -----------------------------------------------------------------
     def dist_connect(self, rank, world, allgather):

@@ -875,6 +875,13 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8])
     out[7] = dev().ready() ? c.earlyCourant : 0;      /* (slot 7 of the device block counts balance decisions: internal) */
     return SF3D_OK;
 }
+sf3d_error_t sf3d_get_sweep_launches(uint64_t* single, uint64_t* paired)
+{
+    if (!single || !paired) return SF3D_PARAMETER_ERROR;
+    const Ctrl& c = dev().ctrl();
+    *single = dev().ready() ? c.singleLaunches : 0; *paired = dev().ready() ? c.pairLaunches : 0;
+    return SF3D_OK;
+}
 double sf3d_get_linear_residual(void) { return dev().ready() ? dev().ctrl().lastNorm : -9999.; }
 double sf3d_get_time_step(void) { return P.dtCurr; }
 sf3d_error_t sf3d_set_time_step(double dt)

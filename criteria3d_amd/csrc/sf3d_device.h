@@ -146,6 +146,11 @@ struct Ctrl {
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
     uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
+    /* paired sweep on a strip (multi GPU): k_sweep_pair leaves the second iteration of the rows next to a neighbouring strip to
+     * k_sweep_bnd, which needs the neighbours' first iterate: pending = 1 between the two launches, x'' goes to pool buffer pairX2 and
+     * the (all-gathered) second norm of the rows k_sweep_pair did itself waits in pairNorm2 */
+    uint32_t pairPending; int32_t pairX2;
+    double pairNorm2;
     uint64_t singleLaunches;  /* k_sweep launches that really ran (next to paired sweeps: the odd iteration of an approximation) */
     uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */
     uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
@@ -232,7 +237,7 @@ struct HeatDev {
     double* lflux[SF3D_FLUX_TYPES];                 /* [10][N] each; allocated per heatFluxSaveMode_t */
 };
 
-/* ---- paired Jacobi sweep (k_sweep_pair): regular NX x NY x NZ grids in layer-major numbering, one GPU -------------------
+/* ---- paired Jacobi sweep (k_sweep_pair): regular NX x NY x NZ grids in layer-major numbering (one GPU, or one row strip of it) ---
  * Per node a 40-bit code, one nibble per link slot: 0..8 = lateral neighbour (dr + 1) * 3 + (dc + 1) of the same layer,
  * 9 = the node above (i - NX NY), 10 = the node below, 15 = no link.  Nodes on the grid's edge fill their lateral slots in
  * their own order (setNodeLink puts the k-th lateral into slot 2 + k), hence a code per node; chunkCode[q] carries the code of
@@ -244,6 +249,8 @@ struct PairGrid {
     uint32_t NX, NY, NZ;                /* 0 when the graph is not such a grid (k_sweep then) */
     uint32_t W;                         /* rows of a block's patch (W - 2 owned rows + one halo row on either side) */
     uint32_t patchCols, patchRows;      /* NX / 64, ceil(NY / (W - 2)) */
+    uint32_t ownLo, ownHi;              /* rows [ownLo, ownHi) of the grid are this rank's (0, NY on one GPU); a row beyond them is the halo row of a
+                                         * neighbouring strip: its x' comes through the window, the second iteration of the rows next to it is k_sweep_bnd's */
     const uint64_t* nodeCode;           /* [N] */
     const uint64_t* chunkCode;          /* [N / 64] */
     /* layered MASKED grids (k_sweep_pair_masked: DEM outlines, soil columns of different depth): NX x NY x NZ is the bounding grid */
@@ -265,6 +272,7 @@ struct DevView {
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
     const uint32_t* asmList;            /* = chunkList: the order the assembly walks the chunks in */
+    const uint32_t* bndList; uint32_t nBnd;   /* multi GPU, paired sweep: the owned chunks that read a neighbouring strip (ChunkDesc::pad0): k_sweep_bnd's rows */
     const uint16_t* lmask;      /* bit s: the node has a link in (device) slot s */
     uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once
                                            per approximation (k_post) instead of once per sweep, off the critical path (SF3D_HALO_DIRECT=0: old way) */

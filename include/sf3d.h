@@ -313,6 +313,11 @@ sf3d_error_t sf3d_set_nodes_boundary_heat(int field, uint32_t count, const uint3
  * result and no other counter).  The "reference" backend cannot count (unmodified sources) and returns
  * SF3D_MISSING_DATA_ERROR. */
 sf3d_error_t sf3d_get_counters(uint64_t out[8]);
+/* How the Jacobi iterations counted in out[3] above were launched by the HIP product since sf3d_initialize: single sweeps (one
+ * iteration per pass over the coefficients) and PAIRED passes (two iterations per pass; on a row strip of a multi-GPU
+ * run: the pass + its boundary launch count as one).  Implementation detail of the product - no result depends on it; the CPU
+ * libraries return SF3D_MISSING_DATA_ERROR. */
+sf3d_error_t sf3d_get_sweep_launches(uint64_t* single_sweeps, uint64_t* paired_passes);
 
 /* Stopping quantity of the LAST linear solve of the water system: Jacobi - the mean scaled update of the last sweep
  * (JacobiWaterCPU's norm, water.cpp:592-600); conjugate gradients (the linealia stand-in) - the relative residual

@@ -67,6 +67,7 @@ res["seconds"] = np.array(time.time() - t0)
 res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
+res["sweep_launches"] = np.array(sf.sweep_launches(), dtype=np.int64)          # (single sweeps, paired passes) of this rank
 np.savez(outfile, **res)
 dist.barrier()
 sf.lib.sf3d_clean()

@@ -151,6 +151,92 @@ def main():
         dist.barrier(); epoch += 1                        # k_props' all-gather
         dist.barrier(); epoch += 1                        # k_assemble's all-gather
         assert np.array_equal(xs[halo], xg[halo]) if len(halo) else True
+    # ---- the PAIRED sweep on a strip (sf3d_pair.inc, DIST): two Jacobi iterations per pass over the coefficients.  The first iterate
+    # of a halo node is its owner's to compute, so the pass is cut in two launches, each closed by an all-gather (= one epoch):
+    #   k_sweep_pair<DIST>  x' of every owned node (foreign neighbours from the window, parity (e - 1) & 1, from the second pass of an
+    #                       approximation on), put at parity e & 1; x'' - from x' of OWNED nodes only - for the nodes of 64-node chunks
+    #                       without a foreign link; both norm partials all-gathered;
+    #   k_sweep_bnd         x'' of the nodes in chunks WITH a foreign link (ChunkDesc::pad0), from x' in memory and the neighbours' x'
+    #                       in the window at parity (e - 1) & 1 (what they put one epoch ago), put at parity e & 1, norm all-gathered
+    #                       and added to the part k_sweep_pair left behind.
+    # An approximation that takes an odd number of iterations ends with a single k_sweep<2>.  Held against the global iteration:
+    # iterate AND both norms, bit for bit (norms: the same terms in rank order).
+    chunk_of = mine // 64
+    has_foreign = foreign.any(axis=0)
+    bnd_chunks = np.unique(chunk_of[has_foreign])
+    in_bnd = np.isin(chunk_of, bnd_chunks)               # k_sweep_bnd's nodes: every owned node of a flagged chunk
+    window = {p: np.full((2, FIELDS, len(recv[p])), np.nan) for p in range(world)}
+    xg = x0.copy(); xs = x0.copy(); xs[owner != rank] = np.nan
+    for p in range(world):
+        xs[recv[p]] = x0[recv[p]]
+    def sweep_rows(sel, xin, from_window):
+        """one Jacobi iteration of the owned nodes `sel` (indices into mine) from xin, foreign neighbours from the window when asked"""
+        rows = mine[sel]
+        out = b[rows].copy()
+        for s in (0, 2, 3, 4, 5, 6, 7, 8, 9, 1):
+            xj = xin[J[s, rows]]
+            if from_window:
+                for c in np.flatnonzero(foreign[s][sel]):
+                    p, k = pos[int(J[s, rows[c]])]
+                    xj[c] = window[p][(epoch - 1) & 1, 0, k]
+            out -= A[s, rows] * xj
+        return out
+    def allsum(v):
+        parts = [None] * world
+        dist.all_gather_object(parts, float(v))
+        t = 0.0
+        for r in range(world): t += parts[r]
+        return t
+    def gnorm(new, old):
+        t = 0.0
+        for r in range(world): t += np.abs(new[owner == r] - old[owner == r]).sum()
+        return t
+    everyone = np.arange(len(mine))
+    for approx, niter in enumerate((6, 5, 1, 4)):
+        it = 0
+        while it < niter:
+            stale = it > 0                                # the halo part of x has not been refreshed since the approximation began
+            xin = xs.copy()
+            if stale: xin[halo] = np.nan
+            if niter - it >= 2:
+                g1 = jacobi_rows(np.arange(m.n), A, J, b, xg); g2 = jacobi_rows(np.arange(m.n), A, J, b, g1)
+                n1g, n2g = gnorm(g1, xg), gnorm(g2, g1)
+                # launch 1: x' everywhere, x'' away from the neighbours
+                x1 = xs.copy(); x1[halo] = np.nan        # x' of a halo node is NOT available inside this launch
+                x1[mine] = sweep_rows(everyone, xin, stale)
+                n1 = np.abs(x1[mine] - xs[mine]).sum()
+                x2 = np.full(m.n, np.nan)
+                inner = np.flatnonzero(~in_bnd)
+                x2[mine[inner]] = sweep_rows(inner, x1, False)      # (NaN would surface if an inner node read a halo node)
+                n2_inner = np.abs(x2[mine[inner]] - x1[mine[inner]]).sum()
+                put(0, lambda p: x1[send[p]])
+                n1t, n2t = allsum(n1), allsum(n2_inner)
+                dist.barrier(); epoch += 1
+                assert n1t == n1g and np.array_equal(x1[mine], g1[mine]), f"paired sweep, approximation {approx} iteration {it}: x'"
+                # launch 2: the nodes next to the neighbours, x' of the neighbours from the window
+                edge = np.flatnonzero(in_bnd)
+                x2[mine[edge]] = sweep_rows(edge, x1, True)
+                n2_edge = np.abs(x2[mine[edge]] - x1[mine[edge]]).sum()
+                xs[mine] = x2[mine]
+                put(0, lambda p: xs[send[p]])
+                n2t = n2t + allsum(n2_edge)
+                dist.barrier(); epoch += 1
+                assert np.array_equal(xs[mine], g2[mine]), f"paired sweep, approximation {approx} iteration {it}: x''"
+                assert abs(n2t - n2g) <= 4e-16 * n2g       # (the second norm is the same terms in another association: inner + edge)
+                xg = g2; it += 2
+            else:                                         # the odd iteration: a single sweep
+                g1 = jacobi_rows(np.arange(m.n), A, J, b, xg)
+                xs[mine] = sweep_rows(everyone, xin, stale)
+                put(0, lambda p: xs[send[p]])
+                dist.barrier(); epoch += 1
+                assert np.array_equal(xs[mine], g1[mine]), f"single sweep after pairs, approximation {approx}"
+                xg = g1; it += 1
+        par_last = (epoch - 1) & 1
+        dist.barrier(); epoch += 1                        # k_post's all-gather
+        for p in range(world):
+            if len(recv[p]): xs[recv[p]] = window[p][par_last, 0]   # k_halo_copy<1>: the halo of the final iterate, once per approximation
+        assert np.array_equal(xs[halo], xg[halo]) if len(halo) else True
+        dist.barrier(); epoch += 1                        # k_props' all-gather
     dist.barrier()
     dist.destroy_process_group()
 
