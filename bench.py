@@ -545,7 +545,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone project (DATA/PROJECT/Ravone: DEM, soil map, soil_ER_2021.db, land use; 13 soil layers to 0.95 m)", "C5DEM": "Ravone DEM with synthetic soils (round-2 stand-in)"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
-                               (f"the 6-hour episode from the initial state; {args.steps} timed hours = {args.steps // EPISODE_HOURS} complete episode(s)" + (f" + {args.steps % EPISODE_HOURS} more hour(s)" if args.steps % EPISODE_HOURS else "") + f" per repetition, {reps} repetitions, `value` = 6 h / median episode" if elapsed_6h else f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)"),
+                               + (f"the 6-hour episode from the initial state; {args.steps} timed hours = {args.steps // EPISODE_HOURS} complete episode(s)" + (f" + {args.steps % EPISODE_HOURS} more hour(s)" if args.steps % EPISODE_HOURS else "") + f" per repetition, {reps} repetitions, `value` = 6 h / median episode" if elapsed_6h else f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)"),
                    "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else (f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI" if replicas is None else f"{world} INDEPENDENT REPLICAS of the workload (the strip exchange could not be set up on this node: {replicas})"),
                    "work": work},
         "repeats_s": rep_elapsed,

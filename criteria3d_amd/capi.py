@@ -141,6 +141,7 @@ SIGNATURES = {
     "sf3d_device_exp": (u8, [u32, pd, pd]),
     "sf3d_device_cbrt": (u8, [u32, pd, pd]),
     "sf3d_get_sweep_launches": (u8, [p64, p64]),
+    "sf3d_get_heat_counters": (u8, [p64]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),
     "sf3d_device_bytes": (u64, []),
     "sf3d_dist_blob_bytes": (i32, []),
@@ -288,6 +289,12 @@ class SF3D:
         if code != OK:
             return None
         return dict(zip(COUNTER_NAMES, [int(v) for v in out]))
+
+    def heat_counters(self):
+        """heat steps accepted / halved, boundary Courant reductions of dtHeat, linear-solver sweeps since sf3d_initialize"""
+        out = (C.c_uint64 * 4)()
+        self.check(self.lib.sf3d_get_heat_counters(out), "get_heat_counters")
+        return dict(zip(("accepted", "halved", "boundary_reductions", "sweeps"), [int(v) for v in out]))
 
     def sweep_launches(self):
         """(single sweeps, paired passes) the product launched since sf3d_initialize"""

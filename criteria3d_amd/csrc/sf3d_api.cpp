@@ -882,6 +882,13 @@ sf3d_error_t sf3d_get_sweep_launches(uint64_t* single, uint64_t* paired)
     *single = dev().ready() ? c.singleLaunches : 0; *paired = dev().ready() ? c.pairLaunches : 0;
     return SF3D_OK;
 }
+sf3d_error_t sf3d_get_heat_counters(uint64_t out[4])
+{
+    if (!out) return SF3D_PARAMETER_ERROR;
+    const Ctrl& c = dev().ctrl();
+    for (int k = 0; k < 4; ++k) out[k] = dev().ready() ? c.heatCounters[k] : 0;
+    return SF3D_OK;
+}
 double sf3d_get_linear_residual(void) { return dev().ready() ? dev().ctrl().lastNorm : -9999.; }
 double sf3d_get_time_step(void) { return P.dtCurr; }
 sf3d_error_t sf3d_set_time_step(double dt)

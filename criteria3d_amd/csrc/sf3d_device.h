@@ -162,8 +162,9 @@ struct Ctrl {
                                * dt - would otherwise pay the check before every approximation for nothing) */
     uint32_t probePad;
     uint64_t earlyCourant;    /* attempts the early Courant check (k_courant_probe) refused before the full properties + assembly ran: a subset of counters[4] */
-    /* ---- work counters (include/sf3d.h sf3d_get_counters) ---- */
+    /* ---- work counters (include/sf3d.h sf3d_get_counters / sf3d_get_heat_counters) ---- */
     uint64_t counters[8];
+    uint64_t heatCounters[4];   /* heat steps accepted / halved (heatLoop returned true / false), boundary Courant reductions of dtHeat, linear-solver sweeps */
 };
 
 /* ---- multi-GPU: one process per GPU, row strips of surface-cell columns --------
@@ -258,6 +259,9 @@ struct PairGrid {
     const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
     const uint32_t* patchList;          /* [blocks] patches that hold nodes: (band of W - 2 rows << 12) | first column (NX <= 4096; else column / 64) */
     const uint8_t* patchDepth;          /* [blocks] layers the patch (halo included) reaches */
+    const uint8_t* role;                /* [N] multi GPU (masked grids): 0 = another rank's node (halo: never computed here), 1 = mine, both iterations in
+                                         * k_sweep_pair_masked, 2 = mine in a chunk that reads a neighbouring strip (ChunkDesc::pad0): first iteration +
+                                         * put there, second iteration in k_sweep_bnd.  null on one GPU */
 };
 
 struct DevView {

@@ -318,6 +318,12 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8]);
  * run: the pass + its boundary launch count as one).  Implementation detail of the product - no result depends on it; the CPU
  * libraries return SF3D_MISSING_DATA_ERROR. */
 sf3d_error_t sf3d_get_sweep_launches(uint64_t* single_sweeps, uint64_t* paired_passes);
+/* Work counters of the heat part since sf3d_initialize (heatLoop, cpusolver.cpp:471-605; computeStep's heat loop,
+ * soilFluxes3D.cpp:1802-1818): out[0] heat steps accepted (heatLoop returned true), [1] heat steps halved (|MBR| > 1: false),
+ * [2] reductions of dtHeat by the boundary Courant rule (updateBoundaryHeatData returned false, heat.cpp:329-339),
+ * [3] sweeps of the linear solver (Gauss-Seidel in the reference and the oracle, Jacobi in the HIP product: not comparable).
+ * The "reference" backend cannot count and returns SF3D_MISSING_DATA_ERROR. */
+sf3d_error_t sf3d_get_heat_counters(uint64_t out[4]);
 
 /* Stopping quantity of the LAST linear solve of the water system: Jacobi - the mean scaled update of the last sweep
  * (JacobiWaterCPU's norm, water.cpp:592-600); conjugate gradients (the linealia stand-in) - the relative residual

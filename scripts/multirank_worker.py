@@ -36,6 +36,11 @@ elif case == "random":
     m, plan = cm.random_model(17, nx=12, ny=40, nz=5), [12.0, (0.0, 30)]
 elif case == "c4f20h0":           # BASELINE config 4's cut: 512 x 512 x 20 in 8 row strips, hour 0 of F20 (22 steps)
     m, plan = cm.catchment_model(512, 512, 20), [20.0]
+elif case == "holes":             # a layered MASKED grid: random holes, columns of different depth, a random subset of the lateral links
+    m, plan = cm.random_model(23, nx=70, ny=45, nz=5), [(30.0, 120), (0.0, 60)]
+elif case == "projwin":           # a window of the Ravone project: DEM outline, four soils, short columns
+    from tests.scenarios import ravone_project_model
+    m, plan = ravone_project_model((980, 1060, 330, 420)), [(25.0, 150), (0.0, 60)]
 elif case == "heat":
     m, plan = cm.with_heat_surface(cm.catchment_model(40, 48, 6, heterogeneous=True)), [4.0, 0.0]
 else:

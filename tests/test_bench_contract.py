@@ -170,6 +170,16 @@ def test_bench_rank_without_a_gpu_stops_the_run():
     assert "no GPU of its own" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_source_compiles_without_warnings():
+    """a SyntaxWarning in bench.py ("'str' object is not callable; perhaps you missed a comma?") is a run-time TypeError on the GPU box:
+    compile the file with warnings as errors here, where no GPU is needed"""
+    import warnings
+    src = (ROOT / "bench.py").read_text()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        compile(src, "bench.py", "exec")
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """--gpus must equal the launcher's WORLD_SIZE; the message says what to do (runs without a GPU: the check comes first)"""
     import os

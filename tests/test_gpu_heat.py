@@ -21,10 +21,11 @@ def rel(a, b, floor=1e-9):
 def run_both(product, oracle, m, heat, rains, max_steps=None):
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        # one oracle thread: with several, the reference's own boundary loop races where a HeatSurface node writes the
-        # evaporation of ponded water into its surface node (water.cpp:729-732, inside an OpenMP for); the serial order
-        # is the defined behaviour and the one the golden vectors pin
-        cm.build(sf, m, threads=1, heat=heat)
+        # (the reference's own boundary loop races with several threads where a HeatSurface node writes the evaporation of
+        # ponded water into its surface node - water.cpp:729-732, inside an OpenMP for; the serial order is the defined behaviour
+        # and the one the golden vectors pin.  The oracle runs that loop in two phases when it has several threads and gives
+        # the serial result bit for bit: oracle/sf3d_oracle.cpp updateBoundary)
+        cm.build(sf, m, threads=8, heat=heat)
     soil = slice(m.ns, m.n)
     for h, mm in enumerate(rains):
         res = []
@@ -204,3 +205,66 @@ def test_heat_half_day(product, oracle):
     rains = [0.0] * (12 if os.environ.get("SF3D_LONG_TESTS") == "1" else 7)
     rains[2] = 3.0; rains[5] = 1.5
     run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), rains)
+
+
+HEAT_COUNTERS = ("accepted", "halved", "boundary_reductions")          # (sweeps: Gauss-Seidel in the oracle, Jacobi on the device - not comparable)
+
+
+def test_heat_project_window_full_hour(product, oracle):
+    """BASELINE config 5's heat clause on the PROJECT (criteria3d_amd/project3d.py: soil map, soil database, land use - not the
+    synthetic soils of test_heat_ravone_window): a 128 x 128 window (rows 600:728 / cols 150:278, three soils, 2 cm top layer), every
+    top soil cell an atmosphere boundary, one FULL hour of coupled water + heat under 20 mm of rain - several hundred computeStep calls,
+    the boundary Courant rule cutting water steps into heat sub-steps.  T, H and the evaporation within 1e-6, identical accepted dt,
+    identical heat sub-step counts (accepted, halved, boundary reductions)."""
+    from tests.scenarios import ravone_project_model
+    m = cm.with_heat_surface(ravone_project_model((600, 728, 150, 278)))
+    assert m.n > 150000
+    run_both(product, oracle, m, cm.Heat(water=True, latent=True, save_mode=0), [20.0])
+    gh, oh = product.heat_counters(), oracle.heat_counters()
+    gc, oc = product.counters(), oracle.counters()
+    assert oc["accepted"] > 300 and oh["accepted"] >= oc["accepted"], (oc, oh)
+    for k in HEAT_COUNTERS:
+        assert gh[k] == oh[k], (k, gh, oh)
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+def test_heat_project_full_size_fifty_steps(product, oracle):
+    """The whole Ravone project (5.85 M nodes) with coupled heat.  The product runs the 20 mm hour alone (water + heat, ~13 s);
+    its state at the hour boundary - H and T of every node and the adaptive time step - goes to both libraries through the state
+    setters (the application's restart path), and both take 50 computeStep calls of the dry hour from there: T and H within 1e-6,
+    identical accepted dt, identical water counters and heat sub-step counts."""
+    from tests.scenarios import ravone_project_model
+    m = cm.with_heat_surface(ravone_project_model(None))
+    heat = cm.Heat(water=True, latent=True, save_mode=0)
+    product.check(product.lib.sf3d_reset_solver_state(), "reset")
+    cm.build(product, m, heat=heat)
+    cm.apply_heat_forcing(product, m, 0)
+    n0, _ = cm.run_hour(product, m, 20.0)
+    assert n0 > 1000
+    H0, T0, dt0 = product.total_potential(0, m.n), product.temperature(0, m.n), product.lib.sf3d_get_time_step()
+    assert np.all(np.isfinite(H0)) and np.all(np.isfinite(T0[m.ns:]))
+    out = []
+    for sf, threads in ((product, 1), (oracle, 16)):
+        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
+        cm.build(sf, m, threads=threads, heat=heat)
+        sf.set_total_potential_bulk(0, H0)
+        sf.set_temperature_bulk(0, T0)
+        sf.check(sf.lib.sf3d_set_time_step(dt0), "set_time_step")
+        sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
+        cm.apply_heat_forcing(sf, m, 1)
+        cb, hb = sf.counters(), sf.heat_counters()
+        _, dts = cm.run_hour(sf, m, 0.0, max_steps=50)
+        ca, ha = sf.counters(), sf.heat_counters()
+        out.append((np.array(dts), sf.temperature(0, m.n)[m.ns:], sf.total_potential(0, m.n),
+                    {k: ca[k] - cb[k] for k in ca}, {k: ha[k] - hb[k] for k in ha}))
+        sf.lib.sf3d_clean()
+    (gd, gT, gH, gc, gh), (od, oT, oH, oc, oh) = out
+    np.testing.assert_allclose(gd, od, rtol=1e-12)
+    assert rel(gT, oT) < RTOL and rel(gH, oH) < RTOL, (rel(gT, oT), rel(gH, oH))
+    for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
+        assert gc[k] == oc[k], (k, gc, oc)
+    for k in HEAT_COUNTERS:
+        assert gh[k] == oh[k], (k, gh, oh)
+    assert oh["accepted"] >= 50

@@ -71,10 +71,11 @@ def oracle_reference(oracle, case):
 def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
     # C4: with the paired sweep on every strip (k_sweep_pair<DIST> + k_sweep_bnd; forced: eight strips of C4 are cache-resident and
     # would keep single sweeps), held against the oracle AND, bit for bit, against the same sharded run with single sweeps
-    pair_env = {"SF3D_PAIR_SWEEP": "1"} if case == "c4f20h0" else None
+    pair_env = {"SF3D_PAIR_SWEEP": "1"} if case in ("c4f20h0", "ravone") else None      # (ravone: k_sweep_pair_masked<DIST> on every strip)
     ranks = run_ranks(world, case, tmp_path, port, env=pair_env)
-    if case == "c4f20h0":
+    if pair_env:
         assert all(int(res["sweep_launches"][1]) > 0 for res in ranks), [res["sweep_launches"] for res in ranks]
+    if case == "c4f20h0":
         single = run_ranks(world, case, tmp_path, port + 20, env={"SF3D_PAIR_SWEEP": "0"})
         assert all(int(res["sweep_launches"][1]) == 0 for res in single)
         own = ranks[0]["owner"]
@@ -110,10 +111,12 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
         assert whole > 3e9 and max(per_rank) < (0.2 if world == 8 else 0.6) * whole, (whole, per_rank)
 
 
-@pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29651, "1"), (3, "c2f60", 29653, "1"), (3, "c2f60", 29655, "0")])
+@pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29651, "1"), (3, "c2f60", 29653, "1"), (3, "c2f60", 29655, "0"),
+                                                   (3, "holes", 29657, "1"), (2, "holes", 29659, "0"), (2, "projwin", 29661, "1")])      # masked grids: k_sweep_pair_masked<DIST>
 def test_paired_sweep_on_strips_is_bitwise_the_single_sweeps(tmp_path, world, case, port, local):
-    """k_sweep_pair<DIST> + k_sweep_bnd on small grids (forced: they are cache-resident), infiltration and runoff regime (Courant
-    refusals, restore-best steps, approximations of odd and even length), strip-local models and the global-index checker mode: every
+    """k_sweep_pair<DIST> / k_sweep_pair_masked<DIST> + k_sweep_bnd on small grids (forced: they are cache-resident), infiltration and
+    runoff regime (Courant refusals, restore-best steps, approximations of odd and even length), full boxes and masked grids (random
+    holes, a window of the Ravone project: strips cut mid-row), strip-local models and the global-index checker mode: every
     owned node's H and Se, every accepted dt and every work counter equal to the run with single sweeps; paired passes on every rank"""
     pair = run_ranks(world, case, tmp_path, port, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6", "SF3D_DIST_LOCAL": local})
     single = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_PAIR_SWEEP": "0", "SF3D_DIST_LOCAL": local})

@@ -49,23 +49,28 @@ def test_twin_is_the_oracle_with_other_elementary_functions(oracle, twin):
     assert 0 < rel_h(out[1][1], out[0][1]) < 1e-6
 
 
-def test_kink_window_two_hours_product_stays_on_the_twin(product, oracle, twin):
+def test_kink_window_product_stays_on_the_twin(product, oracle, twin):
     """The window the suite cannot hold against the glibc oracle (rows 72:200 / cols 300:428: a group of nodes sits at the air-entry
     potential of its soil through the dry hour): the 25 mm hour and the dry hour, in lock step on the product, the twin and the glibc
-    oracle.  Product vs twin: H within 1e-9 and every accepted dt and every work counter identical for the WHOLE two hours.  The
-    glibc oracle, stepped alongside, is only reported: it is where the 1e-6 band is left (if it is left: printed with -s)."""
+    oracle.  Product vs twin: H within 1e-9 and every accepted dt and every work counter identical.  The glibc oracle, stepped
+    alongside, is only reported: it leaves the 1e-6 band - and then the common dt sequence - between steps 600 and 700, ~100 steps
+    into the dry hour.  By default the run stops at step 1 000, well past that point (the product is then 7.7e-4 from the glibc oracle
+    and still ON the twin); SF3D_LONG_TESTS=1 runs the whole two hours (7 262 steps, 12 minutes of oracle time:
+    profiles/r04_sensitivity_product_vs_twin_kink_window.log - product vs twin 0.00e+00, bit for bit, to the end)."""
+    import os
+    limit = 10**9 if os.environ.get("SF3D_LONG_TESTS") == "1" else 1000
     m = ravone_project_model((72, 200, 300, 428))
     libs = (product, twin, oracle)
     for sf in libs:
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=5)
+        cm.build(sf, m, threads=8)
     worst_twin, worst_glibc, steps, glibc_alive = 0.0, 0.0, 0, True
     with ThreadPoolExecutor(3) as pool:          # the three libraries step side by side (ctypes releases the interpreter lock)
         for h, mm in enumerate((25.0, 0.0)):
             for sf in libs:
                 sf.set_sink_source_bulk(0, np.full(m.ns, cm.rain_rate(mm, m.cell_area)))
             t = 0.0
-            while t < 3600.0:
+            while t < 3600.0 and steps < limit:
                 live = libs if glibc_alive else libs[:2]
                 dts = list(pool.map(lambda sf: sf.lib.sf3d_compute_step(3600.0 - t), live))
                 assert dts[0] == dts[1] and dts[0] > 0, (h, steps, dts)
@@ -73,7 +78,7 @@ def test_kink_window_two_hours_product_stays_on_the_twin(product, oracle, twin):
                     glibc_alive = False          # the glibc oracle has taken another decision: from here on it is another trajectory
                     print(f"glibc oracle leaves the common dt sequence at step {steps} (hour {h})")
                 t += dts[0]; steps += 1
-                if steps % 50 == 0 or t >= 3600.0:
+                if steps % 50 == 0 or t >= 3600.0 or steps == limit:
                     Hp, Ht = product.total_potential(0, m.n), twin.total_potential(0, m.n)
                     worst_twin = max(worst_twin, rel_h(Hp, Ht))
                     assert worst_twin < TWIN_RTOL, (h, steps, worst_twin)
@@ -83,7 +88,7 @@ def test_kink_window_two_hours_product_stays_on_the_twin(product, oracle, twin):
                         worst_glibc = max(worst_glibc, rel_h(Hp, oracle.total_potential(0, m.n)))
     print(f"kink window: {steps} steps; product vs twin {worst_twin:.2e}; product vs glibc oracle {worst_glibc:.2e}"
           f"{'' if glibc_alive else ' (until it left the dt sequence)'}")
-    assert steps > 1500
+    assert steps >= min(limit, 1500) and worst_glibc > 1e-6          # (the glibc oracle HAS left the band by then: that is the point)
     gp, gt = cm.snapshot(product, m), cm.snapshot(twin, m)
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
         assert abs(gp[k] - gt[k]) <= 1e-9 * max(abs(gt[k]), 1e-3), (k, gp[k], gt[k])
