@@ -230,41 +230,22 @@ def test_heat_project_window_full_hour(product, oracle):
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 
-def test_heat_project_full_size_fifty_steps(product, oracle):
-    """The whole Ravone project (5.85 M nodes) with coupled heat.  The product runs the 20 mm hour alone (water + heat, ~13 s);
+@pytest.mark.fullsize_background("heat")
+def test_heat_project_full_size_fifty_steps(fullsize_results):
+    """The whole Ravone project (5.85 M nodes) with coupled heat.  The product runs the 20 mm hour alone (water + heat);
     its state at the hour boundary - H and T of every node and the adaptive time step - goes to both libraries through the state
     setters (the application's restart path), and both take 50 computeStep calls of the dry hour from there: T and H within 1e-6,
-    identical accepted dt, identical water counters and heat sub-step counts."""
-    from tests.scenarios import ravone_project_model
-    m = cm.with_heat_surface(ravone_project_model(None))
-    heat = cm.Heat(water=True, latent=True, save_mode=0)
-    product.check(product.lib.sf3d_reset_solver_state(), "reset")
-    cm.build(product, m, heat=heat)
-    cm.apply_heat_forcing(product, m, 0)
-    n0, _ = cm.run_hour(product, m, 20.0)
-    assert n0 > 1000
-    H0, T0, dt0 = product.total_potential(0, m.n), product.temperature(0, m.n), product.lib.sf3d_get_time_step()
-    assert np.all(np.isfinite(H0)) and np.all(np.isfinite(T0[m.ns:]))
-    out = []
-    for sf, threads in ((product, 1), (oracle, 16)):
-        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=threads, heat=heat)
-        sf.set_total_potential_bulk(0, H0)
-        sf.set_temperature_bulk(0, T0)
-        sf.check(sf.lib.sf3d_set_time_step(dt0), "set_time_step")
-        sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
-        cm.apply_heat_forcing(sf, m, 1)
-        cb, hb = sf.counters(), sf.heat_counters()
-        _, dts = cm.run_hour(sf, m, 0.0, max_steps=50)
-        ca, ha = sf.counters(), sf.heat_counters()
-        out.append((np.array(dts), sf.temperature(0, m.n)[m.ns:], sf.total_potential(0, m.n),
-                    {k: ca[k] - cb[k] for k in ca}, {k: ha[k] - hb[k] for k in ha}))
-        sf.lib.sf3d_clean()
-    (gd, gT, gH, gc, gh), (od, oT, oH, oc, oh) = out
-    np.testing.assert_allclose(gd, od, rtol=1e-12)
-    assert rel(gT, oT) < RTOL and rel(gH, oH) < RTOL, (rel(gT, oT), rel(gH, oH))
+    identical accepted dt, identical water counters and heat sub-step counts.  (Runs made by tests/fullsize_worker.py in the
+    background, like the water-only full-size test: tests/conftest.py.)"""
+    assert "heat" in fullsize_results, fullsize_results.get("_log")
+    h = fullsize_results["heat"]
+    f = h["fifty"]
+    assert h["nodes"] > 5_000_000 and h["finite"] and h["hour0_steps"] > 1000 and f["steps"] == 50
+    assert f["dts_equal"]
+    assert f["rel_T"] < RTOL and f["rel_H"] < RTOL, (f["rel_T"], f["rel_H"])
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "restores"):
-        assert gc[k] == oc[k], (k, gc, oc)
+        assert f["work_product"][k] == f["work_checker"][k], (k, f["work_product"], f["work_checker"])
     for k in HEAT_COUNTERS:
-        assert gh[k] == oh[k], (k, gh, oh)
-    assert oh["accepted"] >= 50
+        assert f["heat_work_product"][k] == f["heat_work_checker"][k], (k, f["heat_work_product"], f["heat_work_checker"])
+    assert f["heat_work_checker"]["accepted"] >= 50
+    print(f"full size + heat: T {f['rel_T']:.2e}, H {f['rel_H']:.2e}; worker: {h['seconds_product']:.0f} s product, {h['seconds_total']:.0f} s in all")

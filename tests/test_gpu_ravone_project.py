@@ -52,39 +52,19 @@ def test_project_window_two_hours_match_oracle(product, oracle, window, min_step
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 
-def _segment(sf, m, H0, dt0, steps, threads=16):
-    """build, take over (H, dt) through the state setters, `steps` computeStep calls of the dry hour: what is compared afterwards"""
-    sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-    cm.build(sf, m, threads=threads)
-    sf.set_total_potential_bulk(0, H0)
-    sf.check(sf.lib.sf3d_set_time_step(dt0), "set_time_step")
-    sf.check(sf.lib.sf3d_initialize_balance(), "initialize_balance")
-    base = sf.counters()
-    _, dts = cm.run_hour(sf, m, 0.0, max_steps=steps)
-    c = sf.counters()
-    return {"dts": np.array(dts), "snap": cm.snapshot(sf, m), "work": {k: c[k] - base[k] for k in c}}
+def _check_segment(seg, what, rtol, counters=COUNTERS):
+    assert seg["dts_equal"], (what, "accepted dt sequences differ")
+    assert seg["rel_H"] < rtol, (what, seg["rel_H"])
+    assert seg["abs_Se"] < max(rtol, 1e-9), (what, seg["abs_Se"])
+    for q, (g, o) in seg["scalars"].items():
+        assert abs(g - o) <= rtol * max(abs(o), 1e-3), (what, q, g, o)
+    for q in counters:
+        assert seg["work_product"][q] == seg["work_checker"][q], (what, q, seg["work_product"], seg["work_checker"])
+    return seg["rel_H"]
 
 
-def _continue(sf, m, steps, base):
-    """`steps` more computeStep calls of the dry hour on a model that is already running"""
-    _, dts = cm.run_hour(sf, m, 0.0, max_steps=steps)
-    c = sf.counters()
-    return {"dts": np.array(dts), "snap": cm.snapshot(sf, m), "work": {k: c[k] - base[k] for k in c}}
-
-
-def _assert_segment(g, o, what, rtol):
-    np.testing.assert_allclose(g["dts"], o["dts"], rtol=1e-12, err_msg=what)
-    rel = np.max(np.abs(g["snap"]["H"] - o["snap"]["H"]) / np.maximum(np.abs(o["snap"]["H"]), 1e-9))
-    assert rel < rtol, (what, rel)
-    assert np.max(np.abs(g["snap"]["Se"] - o["snap"]["Se"])) < max(rtol, 1e-9), what
-    for q in ("total_water", "storage", "runoff", "drainage", "lateral"):
-        assert abs(g["snap"][q] - o["snap"][q]) <= rtol * max(abs(o["snap"][q]), 1e-3), (what, q, g["snap"][q], o["snap"][q])
-    for q in COUNTERS:
-        assert g["work"][q] == o["work"][q], (what, q, g["work"], o["work"])
-    return rel
-
-
-def test_project_full_size_runoff_regime_matches_oracle(product, oracle):
+@pytest.mark.fullsize_background("water")
+def test_project_full_size_runoff_regime_matches_oracle(fullsize_results):
     """The whole project (5.85 M nodes, 422 282 columns).  The product alone runs the 25 mm hour (1 650 computeStep calls, down to
     dt = 1 s; 6 s of GPU time - the oracle would need an hour); its state at the end of that hour - H of every node and the adaptive
     time step - is handed to the checkers through the state setters (the application's own restart path,
@@ -100,36 +80,17 @@ def test_project_full_size_runoff_regime_matches_oracle(product, oracle):
           product stays on the CPU restatement for the whole stretch;
       (c) after 100 more steps alone the product hands its state over a second time and is held against the glibc oracle for 100
           steps there (restore-best steps at the minimum time step): 1e-6, identical dt and counters.
-    The three checker runs go side by side (8 + 4 + 4 threads: the GPU boxes of this pool give a container 16 CPUs' worth of time)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from tests import checkers
-    m = ravone_project_model(None)
-    assert m.ns == 422282 and m.n > 5_000_000
-    product.check(product.lib.sf3d_reset_solver_state(), "reset")
-    cm.build(product, m)
-    n0, _ = cm.run_hour(product, m, 25.0)
-    warm = product.counters()
-    assert n0 > 1000 and warm["courant_rejections"] > 0
-    H0, dt0 = product.total_potential(0, m.n), product.lib.sf3d_get_time_step()
-    assert np.all(np.isfinite(H0))
-    g80 = _segment(product, m, H0, dt0, 50)
-    base = {k: product.counters()[k] - g80["work"][k] for k in g80["work"]}
-    g300 = _continue(product, m, 250, base)                      # steps 51 .. 300 of the same run: uninterrupted
-    g300["dts"] = np.concatenate([g80["dts"], g300["dts"]])
-    cm.run_hour(product, m, 0.0, max_steps=100)
-    H1, dt1 = product.total_potential(0, m.n), product.lib.sf3d_get_time_step()
-    late = _segment(product, m, H1, dt1, 100)
-    product.lib.sf3d_clean()
-    twin, second = checkers.load_oracle_fastmath(), checkers.load_oracle_copy("second")
-    with ThreadPoolExecutor(3) as pool:          # (ctypes calls release the interpreter lock)
-        j_twin = pool.submit(_segment, twin, m, H0, dt0, 300, 8)
-        j_pin = pool.submit(_segment, oracle, m, H0, dt0, 50, 4)
-        j_late = pool.submit(_segment, second, m, H1, dt1, 100, 4)
-        o80, o_late, t300 = j_pin.result(), j_late.result(), j_twin.result()
-    r_pin = _assert_segment(g80, o80, "glibc oracle, steps 1-50 from the hour boundary", 1e-6)
-    r_late = _assert_segment(late, o_late, "glibc oracle, 100 steps from the second hand-over", 1e-6)
-    r_twin = _assert_segment(g300, t300, "fast-math twin, 300 uninterrupted steps", 1e-9)
-    print(f"full size: vs glibc oracle {r_pin:.2e} (50 steps), {r_late:.2e} (late 100); vs twin {r_twin:.2e} (300 uninterrupted)")
-    assert o_late["work"]["restores"] + t300["work"]["restores"] > 0
-    for sf in (oracle, second, twin):
-        sf.lib.sf3d_clean()
+    The runs themselves - seconds of GPU time, minutes of oracle time (6 + 3 + 3 threads side by side) - are made by
+    tests/fullsize_worker.py, a background process that tests/conftest.py starts right after collection: this test runs last and
+    only reads the metrics."""
+    assert "water" in fullsize_results, fullsize_results.get("_log")
+    w = fullsize_results["water"]
+    assert w["surface_nodes"] == 422282 and w["nodes"] > 5_000_000 and w["finite"]
+    assert w["hour0_steps"] > 1000 and w["hour0_courant_rejections"] > 0
+    assert w["pin"]["steps"] == 50 and w["twin"]["steps"] == 300 and w["late"]["steps"] == 100
+    r_pin = _check_segment(w["pin"], "glibc oracle, steps 1-50 from the hour boundary", 1e-6)
+    r_late = _check_segment(w["late"], "glibc oracle, 100 steps from the second hand-over", 1e-6)
+    r_twin = _check_segment(w["twin"], "fast-math twin, 300 uninterrupted steps", 1e-9)
+    print(f"full size: vs glibc oracle {r_pin:.2e} (50 steps), {r_late:.2e} (late 100); vs twin {r_twin:.2e} (300 uninterrupted); "
+          f"worker: {w['seconds_product']:.0f} s product, {w['seconds_total']:.0f} s in all")
+    assert w["late"]["work_checker"]["restores"] + w["twin"]["work_checker"]["restores"] > 0
