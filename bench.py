@@ -40,7 +40,7 @@ sys.path.insert(0, str(ROOT))
 import numpy as np  # noqa: E402
 
 WORKLOADS = {"C2": (64, 64, 10), "C3": (256, 256, 15), "C4": (512, 512, 20),
-             "C4H": (512, 256, 20), "C4Q": (512, 128, 20),      # one of two / of four strips of C4 as a grid of its own (tuning the per-rank kernels on one GPU)
+             "C4H": (512, 256, 20), "C4Q": (512, 128, 20), "C4E": (512, 64, 20),      # one of two / four / eight strips of C4 as a grid of its own (tuning the per-rank kernels on one GPU)
              "C5S": (519, 1208, 15),      # synthetic Ravone-like DEM (irregular outline, soil of varying depth)
              "C5": (519, 1208, 14),       # BASELINE config 5: the Ravone PROJECT (DEM + soil map + soil DB + land use, criteria3d_amd/project3d.py)
              "C5DEM": (519, 1208, 15)}    # round-2 stand-in: the Ravone DEM with synthetic soils (kept for comparison with round-2 numbers)

@@ -130,6 +130,8 @@ struct Ctrl {
     double hOuterDt, hOuterSum;   /* dtHeat / dtHeatSum of computeStep's loop                            */
     double hMaxStep, hDt, hDone;  /* maxTimeStep / dtHeat / sumHeatTime of CPUSolver::run(Heat)          */
     double hCourant, hNorm;
+    double hCacheDt;          /* heat step the cached water contents of k_heat_props (HeatDev::thAvgC / thNewC) belong to: H at the heat time level
+                               * depends on dtHeat / dtWater only, so sub-steps of equal length - what the boundary Courant rule produces - share them */
     unsigned long long hNormBits;   /* running maximum of |dx| of a Gauss-Seidel sweep (bit pattern of a non-negative double) */
     HeatBalanceDev heatCur, heatPrev;
     double heatPeriodSink;    /* balanceDataCurrentPeriod.heatSinkSource                                 */
@@ -229,6 +231,7 @@ struct HeatDev {
     /* per-node conductivities evaluated once per node instead of once per link end (same arguments => same bits) */
     const double* airP;                             /* [N] computePressure_fromAltitude(z): a pow of a static input, evaluated once per node */
     double* thetaOld;                               /* [N] theta(Hold - z): constant over the heat sub-steps of one water step */
+    double *thAvgC, *thNewC;                        /* [N] theta(mean h) and theta(H - z) at the heat time level of Ctrl::hCacheDt */
     double *kHeat, *kIsoVap, *hAvg;                 /* heat process: Campbell conductivity, isothermal vapour conductivity at (T, mean h); mean h */
     double *wThLiq, *wThVap, *wTm;                  /* water process: thermal liquid / vapour conductivity at (mean T, H - z); mean T */
     /* atmosphere boundary (HeatSurface nodes) and fixed-temperature boundary, full-length arrays */
