@@ -551,7 +551,7 @@ def main():
         "repeats_s": rep_elapsed,
         "headline_6h": ({"value": EPISODE_HOURS / elapsed_6h, "unit": "sim-h/s", "hours": "one complete episode, hours 0-5 (SURVEY.md 8d headline workload) = `value`",
                          "elapsed_s": elapsed_6h, "episodes_s": rep_episodes} if elapsed_6h else None),
-        "timed_region": {"hours": args.steps, "elapsed_s": elapsed, "hours_per_s": args.steps / elapsed,
+        "timed_region": {"hours": args.steps, "elapsed_s": elapsed, "hours_per_s": args.steps / elapsed, "per_hour_s_last_rep": ph,
                          "note": "all K timed hours (median repetition): complete episodes plus the first K mod 6 hours of one more"},
         "inclusive_value": args.steps / elapsed_incl if elapsed_incl > 0 else None,
         "value_timing": f"median of {reps} repetitions of the timed region; repetition 0 carries the HIP-event sampling of the dominant kernel "
