@@ -12,6 +12,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU comparison")
     config.addinivalue_line("markers", "fullsize_background(part): the test reads the results of tests/fullsize_worker.py, started right after collection")
+    config.addinivalue_line("markers", "gpu_timing: compares timings - must not share the GPU with the background worker's product runs (moved towards the end of the suite)")
 
 
 # ---- the two full-size Ravone-project tests: their checker runs (minutes of oracle time) happen in a background process that is
@@ -22,8 +23,9 @@ _BACKGROUND = {}
 
 def pytest_collection_modifyitems(config, items):
     late = [it for it in items if it.get_closest_marker("fullsize_background")]
+    timing = [it for it in items if it.get_closest_marker("gpu_timing")] if late else []      # (the worker's GPU phase is over long before the end of the suite)
     if late:
-        items[:] = [it for it in items if it not in late] + late
+        items[:] = [it for it in items if it not in late and it not in timing] + timing + late
 
 
 def pytest_collection_finish(session):

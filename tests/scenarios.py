@@ -376,3 +376,25 @@ HEAT_SCENARIOS = tuple(k for k in SCENARIOS if k.startswith("heat_"))
 
 def run_scenario(sf, name, threads=1):
     return SCENARIOS[name](sf, threads=threads)
+
+
+_C4_F20 = {}
+
+
+def oracle_c4_f20(oracle, hours):
+    """The oracle's run of the headline workload (C4 512 x 512 x 20, F20) from the initial state, hour by hour: [(accepted dt, snapshot,
+    counters after the hour)].  Three tests of the GPU suite need its hour 0 and one needs all six hours: it is run once per session (the
+    first request for fewer hours than a later one costs a second run) - the oracle takes ~0.6 s per computeStep at this size."""
+    from criteria3d_amd import catchment as cm
+    if len(_C4_F20.get("hours", [])) >= hours:
+        return _C4_F20["model"], _C4_F20["hours"][:hours]
+    m = cm.catchment_model(512, 512, 20)
+    oracle.check(oracle.lib.sf3d_reset_solver_state(), "reset")
+    cm.build(oracle, m, threads=16)
+    out = []
+    for h in range(hours):
+        _, dts = cm.run_hour(oracle, m, cm.FORCINGS["F20"](h))
+        out.append((list(dts), cm.snapshot(oracle, m), oracle.counters()))
+    oracle.lib.sf3d_clean()
+    _C4_F20.update(model=m, hours=out)
+    return m, out

@@ -112,6 +112,7 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_timing          # (compares two timings: run when nothing else is on the GPU - tests/conftest.py moves it behind the background worker's GPU phase)
 def test_bench_value_is_the_six_hour_episode_whatever_steps_is():
     """the driver runs `--steps 20 --warmup 5`: the timed hours walk through the 6-hour episode of SURVEY 8d again and again (rewound
     outside the clock), `value` is 6 h over the median COMPLETE episode - the 8d headline - and does not depend on --steps"""

@@ -119,7 +119,10 @@ def _snap_close(g, o, tag, se_tol=1e-6, long_run=False):
 
 def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     """BASELINE config 3 in its own regime: 256x256x15, 60 mm in hour 0 - St-Venant runoff with Courant
-    rejections coupled to the subsurface - then the first 1 000 steps of hour 1 (dt at and near dtmin, restore-best steps among them)."""
+    rejections coupled to the subsurface - then the first 300 steps of hour 1 (dt at and near dtmin, restore-best steps among them;
+    1 000 steps with SF3D_LONG_TESTS=1: 46 restore-best calls, run in round 3 - 75 s of oracle time)."""
+    import os
+    LONG_STEPS = 1000 if os.environ.get("SF3D_LONG_TESTS") == "1" else 300
     m = cm.catchment_model(256, 256, 15)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
@@ -128,17 +131,17 @@ def test_c3_f60_runoff_regime_matches_oracle(product, oracle):
     for sf in (product, oracle):
         n0, d0 = cm.run_hour(sf, m, 60.0)
         s0 = cm.snapshot(sf, m)
-        n1, d1 = cm.run_hour(sf, m, 0.0, max_steps=1000)
+        n1, d1 = cm.run_hour(sf, m, 0.0, max_steps=LONG_STEPS)
         res.append((d0, s0, d1, cm.snapshot(sf, m), sf.counters()))
     (gd0, gs0, gd1, gs1, gc), (od0, os0, od1, os1, oc) = res
     assert len(gd0) == len(od0) == 76                     # step counts are grid-size independent on this catchment
     np.testing.assert_allclose(gd0, od0, rtol=1e-12)
     np.testing.assert_allclose(gd1, od1, rtol=1e-12)
     _snap_close(gs0, os0, "C3 F60 h0")
-    _snap_close(gs1, os1, "C3 F60 h1[:1000]", se_tol=1e-5, long_run=True)
+    _snap_close(gs1, os1, f"C3 F60 h1[:{LONG_STEPS}]", se_tol=1e-5, long_run=True)
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
-    assert gc["courant_rejections"] > 0 and gc["restores"] >= 40        # (at this size the dry hour accepts most steps normally: 46 restore-best calls in 1 000 steps; C2 F60 below goes through 8 800)
+    assert gc["courant_rejections"] > 0 and gc["restores"] >= (40 if LONG_STEPS == 1000 else 1)        # (at this size the dry hour accepts most steps normally: 46 restore-best calls in 1 000 steps; C2 F60 below goes through 8 800)
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
 
 
@@ -165,31 +168,32 @@ def test_c4_f60_hour0_matches_oracle(product, oracle):
 def test_c4_f20_all_six_hours_match_oracle(product, oracle):
     """the workload the headline is quoted on (C4 512x512x20, F20, 6 simulated hours): H, Se, storage and boundary sums after
     every hour, identical accepted-dt sequences and work counters"""
-    m = cm.catchment_model(512, 512, 20)
-    for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=16)
+    from tests.scenarios import oracle_c4_f20
+    m, ref = oracle_c4_f20(oracle, 6)          # (run once per session: the full-size and the sharded tests reuse its hour 0)
+    product.check(product.lib.sf3d_reset_solver_state(), "reset")
+    cm.build(product, m)
     steps = []
-    for h in range(6):
-        mm = cm.FORCINGS["F20"](h)
-        _, gd = cm.run_hour(product, m, mm)
+    for h, (od, o, _) in enumerate(ref):
+        _, gd = cm.run_hour(product, m, cm.FORCINGS["F20"](h))
         g = cm.snapshot(product, m)
-        _, od = cm.run_hour(oracle, m, mm)
-        o = cm.snapshot(oracle, m)
         np.testing.assert_allclose(gd, od, rtol=1e-12)
         _snap_close(g, o, f"C4 F20 h{h}")
         steps.append(len(gd))
     assert steps[:2] == [22, 13] and sum(steps) >= 47          # hours 0 and 1 as at 64x64 (SURVEY 8c); 3 steps in hour 2 at this size
-    gc, oc = product.counters(), oracle.counters()
+    gc, oc = product.counters(), ref[-1][2]
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
-    oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+    product.lib.sf3d_clean()
 
 
 @pytest.mark.slow
 def test_c2_f60_three_hours_stay_within_tolerance(product, oracle):
     """the long runoff-regime run DESIGN.md quotes: 3 simulated hours of C2 F60 (about 10 000 accepted steps, almost all through
-    restoreBestStep at dtmin) - every accepted dt and every counter identical, H within 1e-6 at the end of every hour"""
+    restoreBestStep at dtmin) - every accepted dt and every counter identical, H within 1e-6 at the end of every hour.
+    Opt-in (SF3D_LONG_TESTS=1: 35-50 s, oracle-bound); its first hour and 150 steps of the second run in test_gpu_parity.py."""
+    import os
+    if os.environ.get("SF3D_LONG_TESTS") != "1":
+        pytest.skip("long run: SF3D_LONG_TESTS=1")
     m = cm.catchment_model(64, 64, 10)
     for sf in (product, oracle):
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")

@@ -16,24 +16,22 @@ def c4():
 
 
 def test_c4_hour0_matches_oracle(product, oracle, c4):
-    m = c4
-    for sf in (product, oracle):
-        sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, m, threads=16)
+    from tests.scenarios import oracle_c4_f20
+    m, ref = oracle_c4_f20(oracle, 1)
+    od, o, oc = ref[0]
+    product.check(product.lib.sf3d_reset_solver_state(), "reset")
+    cm.build(product, m)
     gs, gd = cm.run_hour(product, m, 20.0)
     g = cm.snapshot(product, m)
-    os_, od = cm.run_hour(oracle, m, 20.0)
-    o = cm.snapshot(oracle, m)
-    assert gs == os_ == 22
+    assert gs == len(od) == 22
     np.testing.assert_allclose(gd, od, rtol=1e-12)
     assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6
     assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
         assert abs(g[k] - o[k]) <= 1e-6 * max(abs(o[k]), 1e-3), (k, g[k], o[k])
-    gc, oc = product.counters(), oracle.counters()
+    gc = product.counters()
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections"):
         assert gc[k] == oc[k], (k, gc, oc)
-    oracle.lib.sf3d_clean()
 
 
 def test_c4_mass_conservation_and_reproducibility(product, c4):

@@ -186,14 +186,22 @@ def test_reference_order_gauss_seidel_equals_jacobi(product, oracle, monkeypatch
     monkeypatch.setenv("SF3D_HEAT_GS", "1")
     gs = run(product)
     monkeypatch.delenv("SF3D_HEAT_GS")
+    rb = run(product)                                    # the default: Gauss-Seidel in two colours (odd layers, then even layers)
+    rb_sweeps = product.heat_counters()["sweeps"]
+    monkeypatch.setenv("SF3D_HEAT_SWEEP", "jacobi")
     jac = run(product)
+    jac_sweeps = product.heat_counters()["sweeps"]
+    monkeypatch.delenv("SF3D_HEAT_SWEEP")
     ref = run(oracle)
-    for (gd, gT, gH), (jd, jT, jH), (od, oT, oH) in zip(gs, jac, ref):
-        np.testing.assert_allclose(gd, od, rtol=1e-12); np.testing.assert_allclose(jd, od, rtol=1e-12)
-        print(f"GS vs oracle {rel(gT, oT):.2e}  Jacobi vs oracle {rel(jT, oT):.2e}  Jacobi vs GS {rel(jT, gT):.2e}")
+    for (gd, gT, gH), (bd, bT, bH), (jd, jT, jH), (od, oT, oH) in zip(gs, rb, jac, ref):
+        np.testing.assert_allclose(gd, od, rtol=1e-12); np.testing.assert_allclose(jd, od, rtol=1e-12); np.testing.assert_allclose(bd, od, rtol=1e-12)
+        print(f"GS vs oracle {rel(gT, oT):.2e}  two-colour vs oracle {rel(bT, oT):.2e}  Jacobi vs oracle {rel(jT, oT):.2e}  two-colour vs GS {rel(bT, gT):.2e}  Jacobi vs GS {rel(jT, gT):.2e}")
         assert rel(gT, oT) < 1e-7, rel(gT, oT)           # same sweep order as the reference: libm last-ulp differences, amplified by the scheme
         assert rel(jT, gT) < 1e-7, rel(jT, gT)           # Jacobi vs Gauss-Seidel: both within the stopping tolerance of the solution
-        assert rel(gH, oH) < 1e-7 and rel(jH, oH) < RTOL
+        assert rel(bT, gT) < 1e-7, rel(bT, gT)           # and so is the two-colour sweep
+        assert rel(gH, oH) < 1e-7 and rel(jH, oH) < RTOL and rel(bH, oH) < RTOL
+    print(f"heat sweeps: two-colour {rb_sweeps}, Jacobi {jac_sweeps}")
+    assert rb_sweeps < jac_sweeps                        # the point of the colours: fewer sweeps to the same tolerance
 
 
 def test_heat_half_day(product, oracle):
