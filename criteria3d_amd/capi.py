@@ -144,6 +144,7 @@ SIGNATURES = {
     "sf3d_get_heat_counters": (u8, [p64]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),
     "sf3d_device_bytes": (u64, []),
+    "sf3d_host_bytes": (u64, []),
     "sf3d_dist_blob_bytes": (i32, []),
     "sf3d_dist_prepare": (u8, [i32, i32]),
     "sf3d_dist_export": (u8, [vp]),

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "sf3d_model.h"
 
@@ -133,10 +135,12 @@ double nodePsi(uint32_t i)                                          /* :140-158 
 struct LocalModel {
     bool on = false;                 /* decided at sf3d_dist_prepare */
     bool built = false;
+    bool trimmed = false;            /* trimHostStaging() has run: M holds this rank's nodes only (the other pages were given back) */
     HostModel L;
     std::vector<uint32_t> l2g;
     std::vector<int32_t> g2l;
     Partition part;                  /* local indices */
+    Partition gpart;                 /* global indices: what sf3d_dist_owner / sf3d_dist_halo answer from once M is trimmed */
 };
 LocalModel LM;
 int distRank = 0, distWorld = 1;
@@ -156,9 +160,10 @@ template <class T> void scatterFrom(std::vector<T>& dst, const std::vector<T>& s
 /* (re)build L from M: the rank's nodes, links remapped, partition in local indices */
 sf3d_error_t buildLocal()
 {
-    Partition gp;
+    Partition& gp = LM.gpart;
     sf3d_error_t e = sf3d_compute_partition(M, distRank, distWorld, gp);
     if (e != SF3D_OK) return e;
+    LM.trimmed = false;
     std::vector<uint8_t> in(M.N, 0);
     for (uint32_t i = 0; i < M.N; ++i) if (gp.owner[i] == distRank) in[i] = 1;
     for (int p = 0; p < distWorld; ++p) for (uint32_t i : gp.recv[p]) in[i] = 1;
@@ -213,6 +218,65 @@ sf3d_error_t buildLocal()
     LM.built = true;
     return SF3D_OK;
 }
+
+/* ---- host staging per rank -----------------------------------------------------------------------------------------------------
+ * The caller builds the GLOBAL model on every rank (the API is global).  Once the ranks are connected the topology is frozen (an
+ * edit is an error until a new prepare / export / connect round), so the global staging copy M is only ever read and written at
+ * THIS rank's nodes - gathers into L, scatters out of it, setters of its own nodes.  trimHostStaging() then gives the pages of every
+ * array of M that hold only OTHER ranks' nodes back to the system (madvise MADV_DONTNEED: the vectors stay valid, the pages read as
+ * zero and are re-faulted if a caller insists on writing there - bulk setters skip such nodes) and frees the arrays of L that only the
+ * graph build reads (coordinates, link tables, areas).  What stays resident per rank is its strip + halo: at eight ranks of C4 about a
+ * fifth of the single-rank figure (sf3d_host_bytes, asserted in tests/test_gpu_multirank.py).  Partition queries answer from the copy
+ * kept in LM.gpart. */
+template <class F> void forEachArray(HostModel& h, F f)
+{
+    f(h.x); f(h.y); f(h.z); f(h.size); f(h.surf); f(h.hasClass); f(h.cls); f(h.btype); f(h.bslope); f(h.bsize); f(h.bflowRate); f(h.bflowSum);
+    f(h.prescribed); f(h.nLat);
+    for (int s = 0; s < SF3D_SLOTS; ++s) { f(h.ltype[s]); f(h.lto[s]); f(h.larea[s]); f(h.lflowSum[s]); }
+    f(h.Se); f(h.K); f(h.H); f(h.sink); f(h.pond);
+    f(h.temperature); f(h.heatSink); f(h.bHeightWind); f(h.bHeightT); f(h.bRoughH); f(h.bT); f(h.bRH); f(h.bWind); f(h.bNetIrr); f(h.bFixT); f(h.bFixDepth);
+    f(h.bAero); f(h.bSoilCond); f(h.bSens); f(h.bLat); f(h.bRad); f(h.bAdv);
+    for (int t = 0; t < SF3D_FLUX_TYPES; ++t) f(h.lfluxCache[t]);
+}
+template <class T> void releasePages(std::vector<T>& v, size_t a, size_t b)      /* elements [a, b): whole pages inside the range */
+{
+    if (v.size() < b || b <= a) return;
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    uintptr_t lo = (uintptr_t)(v.data() + a), hi = (uintptr_t)(v.data() + b);
+    lo = (lo + page - 1) / page * page; hi = hi / page * page;
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_DONTNEED);
+}
+template <class T> uint64_t residentBytes(const std::vector<T>& v)
+{
+    if (v.empty()) return 0;
+    const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+    const uintptr_t lo = (uintptr_t)v.data() / page * page, hi = ((uintptr_t)(v.data() + v.size()) + page - 1) / page * page;
+    std::vector<unsigned char> vec((hi - lo) / page);
+    if (mincore((void*)lo, hi - lo, vec.data()) != 0) return (uint64_t)v.size() * sizeof(T);
+    uint64_t n = 0;
+    for (unsigned char c : vec) n += c & 1u;
+    return n * page;
+}
+void trimHostStaging()
+{
+    if (!LM.on || !LM.built || LM.trimmed || LM.g2l.size() != M.N) return;
+    if (const char* e = getenv("SF3D_DIST_TRIM_HOST")) if (e[0] == '0') return;
+    std::vector<std::pair<size_t, size_t>> runs;          /* maximal runs of nodes that are not this rank's (owned or halo) */
+    for (size_t i = 0; i < M.N;) {
+        if (LM.g2l[i] >= 0) { ++i; continue; }
+        size_t j = i;
+        while (j < M.N && LM.g2l[j] < 0) ++j;
+        if (j - i >= 512) runs.push_back({i, j});
+        i = j;
+    }
+    forEachArray(M, [&](auto& v) { if (v.size() >= M.N) for (auto& r : runs) releasePages(v, r.first, r.second); });
+    HostModel& L = LM.L;                                  /* read by the graph build only: no rebuild while connected */
+    auto drop = [](auto& v) { std::remove_reference_t<decltype(v)>().swap(v); };
+    drop(L.x); drop(L.y); drop(L.z); drop(L.size); drop(L.surf); drop(L.hasClass); drop(L.cls); drop(L.nLat);
+    for (int s = 0; s < SF3D_SLOTS; ++s) { drop(L.ltype[s]); drop(L.lto[s]); drop(L.larea[s]); }
+    LM.trimmed = true;
+}
+inline bool skippedByTrim(uint32_t i) { return LM.trimmed && i < LM.g2l.size() && LM.g2l[i] < 0; }
 
 bool needState(); bool needFlows(); bool needHeatState();
 /* the model the device works on, brought up to date with what the setters changed in M since the last call */
@@ -309,7 +373,7 @@ sf3d_error_t sf3d_clean(void)                                       /* soilFluxe
     if (!M.initialized) return SF3D_OK;
     dev().release();
     M = HostModel();
-    LM.built = false; LM.L = HostModel(); LM.l2g.clear(); LM.g2l.clear();       /* (LM.on stays: sf3d_dist_prepare comes before sf3d_initialize) */
+    LM.built = false; LM.trimmed = false; LM.L = HostModel(); LM.l2g.clear(); LM.g2l.clear(); LM.gpart = Partition();       /* (LM.on stays: sf3d_dist_prepare comes before sf3d_initialize) */
     return SF3D_OK;
 }
 
@@ -839,7 +903,7 @@ sf3d_error_t sf3d_set_node_links(uint64_t count, const uint32_t* node, const uin
 }
 #define BULK_SET(NAME, CALL, ...)                                                     \
     sf3d_error_t NAME(uint32_t first, uint32_t count, __VA_ARGS__)                     \
-    { for (uint32_t k = 0; k < count; ++k) { sf3d_error_t e = CALL; if (e != SF3D_OK) return e; } return SF3D_OK; }
+    { for (uint32_t k = 0; k < count; ++k) { if (skippedByTrim(first + k)) continue; sf3d_error_t e = CALL; if (e != SF3D_OK) return e; } return SF3D_OK; }
 BULK_SET(sf3d_set_nodes_soil, sf3d_set_node_soil(first + k, s[k], h ? h[k] : 0), const uint16_t* s, const uint16_t* h)
 BULK_SET(sf3d_set_nodes_surface, sf3d_set_node_surface(first + k, s[k]), const uint16_t* s)
 BULK_SET(sf3d_set_nodes_pond, sf3d_set_node_pond(first + k, v[k]), const double* v)
@@ -848,7 +912,7 @@ BULK_SET(sf3d_set_nodes_total_potential, sf3d_set_node_total_potential(first + k
 BULK_SET(sf3d_set_nodes_water_sink_source, sf3d_set_node_water_sink_source(first + k, v[k]), const double* v)
 #define BULK_GET(NAME, CALL)                                                          \
     sf3d_error_t NAME(uint32_t first, uint32_t count, double* out)                     \
-    { for (uint32_t k = 0; k < count; ++k) out[k] = CALL(first + k); return SF3D_OK; }
+    { for (uint32_t k = 0; k < count; ++k) out[k] = skippedByTrim(first + k) ? SF3D_NODATA : CALL(first + k); return SF3D_OK; }      /* (another rank's node: sf3d_dist_owner says whose) */
 BULK_GET(sf3d_get_nodes_total_potential, sf3d_get_node_total_potential)
 BULK_GET(sf3d_get_nodes_degree_of_saturation, sf3d_get_node_degree_of_saturation)
 BULK_GET(sf3d_get_nodes_water_content, sf3d_get_node_water_content)
@@ -954,13 +1018,25 @@ sf3d_error_t sf3d_dist_finalize(int use_rccl)
 {
     sf3d_error_t e = dev().dist_finalize(use_rccl != 0);
     if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_finalize: %s\n", dev().last_error());
+    else trimHostStaging();          /* connected: the topology is frozen, M is needed at this rank's nodes only */
     return e;
+}
+uint64_t sf3d_host_bytes(void)
+{
+    uint64_t n = 0;
+    forEachArray(M, [&](auto& v) { n += residentBytes(v); });
+    if (LM.on) forEachArray(LM.L, [&](auto& v) { n += residentBytes(v); });
+    return n;
 }
 /* partition queries are host logic: they work without a device */
 sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* out)
 {
     if (!M.initialized) return SF3D_MEMORY_ERROR;
     if ((uint64_t)first + count > M.N) return SF3D_INDEX_ERROR;
+    if (LM.trimmed && world == distWorld && LM.gpart.owner.size() == M.N) {      /* (M no longer holds the other ranks' links) */
+        for (uint32_t k = 0; k < count; ++k) out[k] = LM.gpart.owner[first + k];
+        return SF3D_OK;
+    }
     Partition part;
     sf3d_error_t e = sf3d_compute_partition(M, 0, world, part);
     if (e != SF3D_OK) return e;
@@ -1028,9 +1104,14 @@ sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32
     if (!M.initialized) return SF3D_MEMORY_ERROR;
     if (peer < 0 || peer >= world) return SF3D_PARAMETER_ERROR;
     Partition part;
-    sf3d_error_t e = sf3d_compute_partition(M, rank, world, part);
-    if (e != SF3D_OK) return e;
-    const std::vector<uint32_t>& l = direction == 0 ? part.send[peer] : part.recv[peer];
+    const bool cached = LM.trimmed && world == distWorld && rank == distRank && (int)LM.gpart.send.size() == world;      /* (M no longer holds the other ranks' links) */
+    if (!cached) {
+        if (LM.trimmed) return SF3D_MISSING_DATA_ERROR;          /* another rank's lists cannot be derived from a trimmed staging copy */
+        sf3d_error_t e = sf3d_compute_partition(M, rank, world, part);
+        if (e != SF3D_OK) return e;
+    }
+    const Partition& pp = cached ? LM.gpart : part;
+    const std::vector<uint32_t>& l = direction == 0 ? pp.send[peer] : pp.recv[peer];
     *count = (uint32_t)l.size();
     if (out) { if (capacity < l.size()) return SF3D_MEMORY_ERROR; std::copy(l.begin(), l.end(), out); }
     return SF3D_OK;

@@ -386,6 +386,11 @@ sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, d
 /* bytes of device memory behind the model's arrays on this rank (0 for libraries without a device); with strip-local device models
  * (default for world > 1; SF3D_DIST_LOCAL=0: every rank uploads the whole global model) about 1 / world of the single-rank figure + halo */
 uint64_t     sf3d_device_bytes(void);
+/* bytes of HOST memory resident behind the library's staging model (the global copy the setters write + a rank's strip-local copy),
+ * counted page by page (mincore).  Multi GPU: once the ranks are connected the pages of the global copy that hold only other ranks'
+ * nodes are given back to the system and the strip-local copy drops what only the graph build reads: a rank of an eight-way C4 run
+ * keeps about a fifth of the single-rank figure (SF3D_DIST_TRIM_HOST=0 keeps everything). */
+uint64_t     sf3d_host_bytes(void);
 int          sf3d_dist_blob_bytes(void);
 sf3d_error_t sf3d_dist_prepare(int rank, int world);
 sf3d_error_t sf3d_dist_export(void* blob_out);

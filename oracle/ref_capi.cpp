@@ -184,6 +184,7 @@ sf3d_error_t sf3d_device_pow(uint32_t, const double*, const double*, double*) { 
 
 /* multi-GPU entry points exist only in the HIP product */
 uint64_t sf3d_device_bytes(void) { return 0; }
+uint64_t sf3d_host_bytes(void) { return 0; }
 int sf3d_dist_blob_bytes(void) { return 0; }
 sf3d_error_t sf3d_dist_prepare(int, int) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_dist_export(void*) { return SF3D_MISSING_DATA_ERROR; }

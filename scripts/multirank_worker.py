@@ -54,7 +54,7 @@ if case not in ("ravone", "c4f20h0"):
     sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
 owner = sf.owner_map(world, m.n)
-res = {"owner": owner}
+res = {"owner": owner, "host_bytes": np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)}      # the library's resident staging memory once connected
 t0 = time.time()
 for h, item in enumerate(plan):
     mm, mx = item if isinstance(item, tuple) else (item, None)
@@ -70,6 +70,7 @@ for h, item in enumerate(plan):
         res[f"{k}_h{h}"] = np.array(s[k])
 res["seconds"] = np.array(time.time() - t0)
 res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
+res["host_bytes_end"] = np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
 res["sweep_launches"] = np.array(sf.sweep_launches(), dtype=np.int64)          # (single sweeps, paired passes) of this rank

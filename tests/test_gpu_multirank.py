@@ -108,9 +108,15 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
         product.check(product.lib.sf3d_reset_solver_state(), "reset")
         cm.build(product, m)
         whole = int(product.lib.sf3d_device_bytes())
+        whole_host = int(product.lib.sf3d_host_bytes())
         product.lib.sf3d_clean()
         per_rank = [int(res["device_bytes"]) for res in ranks]
         assert whole > 3e9 and max(per_rank) < (0.2 if world == 8 else 0.6) * whole, (whole, per_rank)
+        # ... and on the host: once connected, a rank keeps the pages of the staging model that hold ITS nodes (sf3d_host_bytes: resident
+        # pages of the global copy + the strip-local copy) - at eight ranks below a quarter of what one rank holds for the whole grid,
+        # at the start and at the end of the run (bulk setters and getters leave the other ranks' pages alone)
+        host = [max(int(res["host_bytes"]), int(res["host_bytes_end"])) for res in ranks]
+        assert whole_host > 1.5e9 and max(host) < (0.25 if world == 8 else 0.7) * whole_host, (whole_host, host)
 
 
 @pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29651, "1"), (3, "c2f60", 29653, "1"), (3, "c2f60", 29655, "0"),

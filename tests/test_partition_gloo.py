@@ -30,6 +30,7 @@ def test_strips_are_row_blocks_cut_at_chunk_boundaries(product):
     """512-wide grid, 8 ranks: every rank owns 64 full rows of every layer; halos are one row."""
     m = cm.catchment_model(128, 64, 4)
     cm.build(product, m, finalize=False)
+    assert 250 * m.n < int(product.lib.sf3d_host_bytes()) < 600 * m.n          # the resident staging model: ~330 B per node, counted page by page
     owner = product.owner_map(4, m.n).reshape(4, 64, 128)
     for r in range(4):
         assert (owner[:, 16 * r:16 * (r + 1), :] == r).all()           # 64 rows / 4 ranks, all layers (columns stay whole)
