@@ -422,8 +422,12 @@ sf3d_error_t sf3d_initialize_balance(void)                          /* soilFluxe
     c.curStep.MBR = 0.; wholePeriod.MBR = 0.; c.curStep.MBE = 0.; wholePeriod.MBE = 0.;
     dev().push_ctrl();
     needFlows();
-    for (int k = 0; k < SF3D_SLOTS; ++k) std::fill(M.lflowSum[k].begin(), M.lflowSum[k].end(), 0.);
-    std::fill(M.bflowSum.begin(), M.bflowSum.end(), 0.);
+    if (LM.trimmed) {          /* this rank's nodes only: the other pages of the staging copy were given back (and read as zero anyway) */
+        for (uint32_t g : LM.l2g) { for (int k = 0; k < SF3D_SLOTS; ++k) M.lflowSum[k][g] = 0.; M.bflowSum[g] = 0.; }
+    } else {
+        for (int k = 0; k < SF3D_SLOTS; ++k) std::fill(M.lflowSum[k].begin(), M.lflowSum[k].end(), 0.);
+        std::fill(M.bflowSum.begin(), M.bflowSum.end(), 0.);
+    }
     M.flowSumsDirty = true;
     if (M.heat) {                                                   /* initializeHeatBalance, heat.cpp:31-53 */
         double hs = 0.;
