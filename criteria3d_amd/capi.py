@@ -151,6 +151,7 @@ SIGNATURES = {
     "sf3d_dist_connect": (u8, [vp]),
     "sf3d_dist_status": (i32, []),
     "sf3d_dist_finalize": (u8, [i32]),
+    "sf3d_dist_transport": (i32, []),
     "sf3d_get_regular_grid": (u8, [p32, p32, p32, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
     "sf3d_dist_owner": (u8, [i32, u32, u32, C.POINTER(C.c_int32)]),
     "sf3d_dist_halo": (u8, [i32, i32, i32, i32, u32, p32, p32]),
@@ -317,8 +318,12 @@ class SF3D:
         if getattr(self, "legacy_connect", False):      # a launcher without the status / finalize round (tests): windows if they work
             return
         # which exchange: every rank reports whether its windows passed the self-check; one rank that needs RCCL moves all of them
+        # the ranks' common decision: the device windows when every rank's passed their self-check; otherwise the same exchange through
+        # host-memory windows (POSIX shared memory over PCIe: slower, same protocol) - or RCCL, only when SF3D_EXCHANGE=rccl asks for it
         status = allgather(bytes([self.lib.sf3d_dist_status() & 1]))
-        self.check(self.lib.sf3d_dist_finalize(1 if any(b[0] for b in status) else 0), "dist_finalize")
+        failed = any(b[0] for b in status)
+        mode = 0 if not failed else (1 if os.environ.get("SF3D_EXCHANGE") == "rccl" else 2)
+        self.check(self.lib.sf3d_dist_finalize(mode), "dist_finalize")
 
     def owner_map(self, world, n):
         out = np.empty(n, dtype=np.int32)

@@ -1018,13 +1018,15 @@ sf3d_error_t sf3d_dist_connect(const void* blobs)
     return e;
 }
 int sf3d_dist_status(void) { return dev().dist_status(); }
-sf3d_error_t sf3d_dist_finalize(int use_rccl)
+sf3d_error_t sf3d_dist_finalize(int mode)
 {
-    sf3d_error_t e = dev().dist_finalize(use_rccl != 0);
+    if (mode < 0 || mode > 2) return SF3D_PARAMETER_ERROR;
+    sf3d_error_t e = dev().dist_finalize(mode);
     if (e != SF3D_OK) fprintf(stderr, "sf3d: dist_finalize: %s\n", dev().last_error());
     else trimHostStaging();          /* connected: the topology is frozen, M is needed at this rank's nodes only */
     return e;
 }
+int sf3d_dist_transport(void) { return dev().dist_transport(); }
 uint64_t sf3d_host_bytes(void)
 {
     uint64_t n = 0;

@@ -99,6 +99,9 @@ struct DistBlob {
     uint32_t generation, pad;       /* export count of the rank; rank 0's value stamps the self-check token of a connect */
     unsigned char ncclId[128];     /* rank 0: ncclUniqueId of the run's RCCL communicator (all zero when RCCL is not available) */
     char pciBusId[32];             /* which physical GPU the rank runs on (start-up self-check: distinct, peer-reachable devices) */
+    char shmName[48];              /* POSIX shared-memory object holding a second copy of the rank's window in HOST memory: the fall-back
+                                    * transport when the device windows cannot be opened or do not carry device-initiated stores */
+    uint64_t windowBytes;
 };
 
 /* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR
@@ -135,7 +138,8 @@ public:
     sf3d_error_t dist_export(HostModel& m, const ParamsHost& p, DistBlob* out);
     sf3d_error_t dist_connect(const DistBlob* all);
     int dist_status() const { return distStatus_; }
-    sf3d_error_t dist_finalize(bool useRccl);
+    int dist_transport() const;
+    sf3d_error_t dist_finalize(int mode);      /* 0 device windows (all ranks passed), 1 RCCL (opt-in), 2 host-memory windows (fall-back) */
     int world() const { return world_; }
     int rank() const { return rank_; }
     /* instrumentation */

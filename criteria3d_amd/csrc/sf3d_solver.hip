@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      /* types only: the library is dlopen'ed when a multi-GPU run asks for the RCCL exchange */
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>

@@ -395,14 +395,21 @@ int          sf3d_dist_blob_bytes(void);
 sf3d_error_t sf3d_dist_prepare(int rank, int world);
 sf3d_error_t sf3d_dist_export(void* blob_out);
 sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
-/* Which exchange: sf3d_dist_connect opens the peers' windows and checks them (one value through every window, both ways, bounded).
- * sf3d_dist_status() then says what THIS rank found: 0 = its windows work, 1 = they do not (or SF3D_EXCHANGE=rccl asks for RCCL).
- * The launcher all-gathers that one value and calls sf3d_dist_finalize(any rank said 1) on every rank - REQUIRED: the model is not
- * connected before it.  0 keeps the windows.  1 is an error on every rank (some rank's windows failed) unless SF3D_EXCHANGE=rccl opted
- * into the RCCL exchange: then all ranks join the communicator whose id rank 0 put into its blob (collective: ncclCommInitRank) and
- * move halos with ncclSend/ncclRecv and the partial sums with ncclAllGather (coded, not yet run on hardware). */
+/* Which exchange: sf3d_dist_connect opens the peers' windows (device memory, HIP IPC) and checks them (one value through every window,
+ * both ways, bounded).  sf3d_dist_status() then says what THIS rank found: 0 = its windows work, 1 = they do not (or SF3D_EXCHANGE asks
+ * for another transport).  The launcher all-gathers that one value and calls sf3d_dist_finalize(mode) with the SAME mode on every rank -
+ * REQUIRED: the model is not connected before it.
+ *   mode 0  keep the device windows (every rank said 0);
+ *   mode 2  some rank's device windows failed: the same exchange through HOST-MEMORY windows - every rank has published a POSIX
+ *           shared-memory copy of its window in its blob; all ranks map and register them (hipHostRegister) and repeat the self-check
+ *           through them.  Slower (both ends of an exchange cross PCIe), same protocol, same bits.  SF3D_EXCHANGE=host forces it;
+ *   mode 1  only with SF3D_EXCHANGE=rccl: all ranks join the communicator whose id rank 0 put into its blob (collective:
+ *           ncclCommInitRank) and move halos with ncclSend/ncclRecv and the partial sums with ncclAllGather (coded, not yet run on
+ *           hardware); without that opt-in mode 1 is an error on every rank. */
 int          sf3d_dist_status(void);
-sf3d_error_t sf3d_dist_finalize(int use_rccl);
+sf3d_error_t sf3d_dist_finalize(int mode);
+/* which exchange a connected multi-rank model uses: 0 none (one rank, or not connected), 1 device windows, 2 host-memory windows, 3 RCCL */
+int          sf3d_dist_transport(void);
 /* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
 /* Host logic, no device needed: SF3D_OK and the shape if the staged node graph is a regular NX x NY x NZ grid in layer-major
  * numbering i = (l NY + r) NX + c with the ten-link stencil (slot 0 up, 1 down, laterals to the 8-neighbourhood of the layer;

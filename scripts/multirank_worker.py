@@ -54,7 +54,7 @@ if case not in ("ravone", "c4f20h0"):
     sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
 owner = sf.owner_map(world, m.n)
-res = {"owner": owner, "host_bytes": np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)}      # the library's resident staging memory once connected
+res = {"owner": owner, "transport": np.array(int(sf.lib.sf3d_dist_transport())), "host_bytes": np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)}      # the library's resident staging memory once connected
 t0 = time.time()
 for h, item in enumerate(plan):
     mm, mx = item if isinstance(item, tuple) else (item, None)

