@@ -137,6 +137,7 @@ def build_static_dropin(force: bool = False):
 def build_oracle(with_reference: bool = True) -> None:
     """Test infrastructure: the CPU restatement and (when /root/reference is present) oracle/_ref."""
     _run(["make", "-C", str(ROOT / "oracle"), "oracle"])
+    _run(["make", "-C", str(ROOT / "oracle"), "oracle-fm"])        # the fast-math twin (a diagnostic of tests/test_gpu_sensitivity.py, never a pin)
     if with_reference:
         _run(["make", "-C", str(ROOT / "oracle"), "ref"])
         _run(["make", "-C", str(ROOT / "oracle"), "ref-tuned"])
