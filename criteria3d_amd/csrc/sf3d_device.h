@@ -152,7 +152,7 @@ struct Ctrl {
      * k_sweep_bnd, which needs the neighbours' first iterate: pending = 1 between the two launches, x'' goes to pool buffer pairX2 and
      * the (all-gathered) second norm of the rows k_sweep_pair did itself waits in pairNorm2 */
     uint32_t pairPending; int32_t pairX2;
-    double pairNorm2;
+    double pairNorm2, pairNorm2Lo;      /* (a double-double: sf3d_physics.inc "the norm of a Jacobi sweep") */
     uint64_t singleLaunches;  /* k_sweep launches that really ran (next to paired sweeps: the odd iteration of an approximation) */
     uint64_t pairLaunches;    /* k_sweep_pair launches that really ran (guarded no-op launches do not count): event attribution */
     uint32_t asmSeq;          /* counts Courant decisions (= assemblies)                                          */
@@ -176,7 +176,7 @@ struct Ctrl {
  * reader's own arrays by its next decision kernel, which also all-gathers the partial sums through
  * the same windows (system-scope stores + epoch-stamped flags, double-buffered by epoch parity). */
 #define SF3D_MAX_RANKS 16
-struct DistMail { unsigned long long seq; double v[3]; };
+struct DistMail { unsigned long long seq; double v[4]; };      /* (four: both norms of a paired pass, each a double-double) */
 struct DistWindow {                     /* head of each rank's window; payload doubles follow */
     DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
     unsigned long long ping[SF3D_MAX_RANKS];   /* start-up self-check: peer p stores a token here through its mapping of this window */
@@ -323,6 +323,7 @@ struct DevView {
     /* conjugate gradients (null unless the device CG is enabled): diagonal of the un-normalised rows, residual, direction, A p */
     double *cgDiag, *cgR, *cgP, *cgQ;
     double *part0, *part1;              /* per-block partials [nb] */
+    double *part2, *part3;              /* the second norm of a paired pass (both norms are double-doubles: part0/1 and part2/3) */
     unsigned int* arrive;               /* block arrival counter of the fused sweep + decision kernel */
     unsigned int* gridBar;              /* arrival counter of the persistent step kernel's grid barrier (monotonic) */
     const SoilDev* soils;
