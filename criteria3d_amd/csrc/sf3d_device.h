@@ -52,6 +52,7 @@ enum : uint32_t {
 
 /* 16-byte pair; plain struct so host code can use it too */
 struct alignas(16) sf3d_d2 { double x, y; };
+struct alignas(8) sf3d_f2 { float x, y; };
 
 struct SoilDev {        /* soilData_t (types.h:104-121) + per-soil constants */
     double alpha, n, m, he, Sc, invSc, thetaS, thetaR, Ksat, L, invM, mualemDen;
@@ -240,7 +241,8 @@ struct HeatDev {
     /* atmosphere boundary (HeatSurface nodes) and fixed-temperature boundary, full-length arrays */
     const double *bHeightWind, *bHeightT, *bRoughH, *bT, *bRH, *bWind, *bNetIrr, *bFixT, *bFixDepth;
     double *bAero, *bSoilCond, *bSens, *bLat, *bRad, *bAdv;
-    double *lwaterFlux, *lvaporFlux;                /* [10][N], values rounded through float like the reference */
+    sf3d_f2* lwvFlux;                               /* [10][N] (water, vapour) flux of the link: the reference keeps them as floats (heat.cpp saveWaterFluxValues),
+                                                     * one 8-byte pair per link here - half the bytes of two doubles holding the same float values */
     double* lflux[SF3D_FLUX_TYPES];                 /* [10][N] each; allocated per heatFluxSaveMode_t */
 };
 
