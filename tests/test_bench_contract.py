@@ -38,7 +38,10 @@ def test_committed_bench_line_has_every_contract_field():
             # round 4 on: `value` is the 6-hour episode whatever --steps is, the step roofline describes one episode
             assert line["headline_6h"]["value"] == line["value"] and line["timed_region"]["hours"] == line["steps"]
             assert st["region"].startswith("one 6-hour episode") and st["work"]["sweeps"] == 703 and st["traffic"] is not None
-            drv = json.load(open(ROOT / "profiles" / Path(files[-1]).name.replace("_bench.json", "_bench_driver_style_steps20_warmup5.json")))
+            # the driver's own command (--steps 20 --warmup 5), latest committed line of the same round
+            drv_files = sorted(glob.glob(str(ROOT / "profiles" / (Path(files[-1]).name[:3] + "_*_bench_driver_style_steps20_warmup5.json"))))
+            assert drv_files, "no committed driver-style bench line for this round"
+            drv = json.load(open(drv_files[-1]))
             assert drv["steps"] == 20 and abs(drv["value"] - line["value"]) < 0.03 * line["value"], (drv["value"], line["value"])
     else:
         assert 0.5 < r.get("pass_frac", r["frac"]) < 1.0
