@@ -140,6 +140,7 @@ SIGNATURES = {
     "sf3d_device_log": (u8, [u32, pd, pd]),
     "sf3d_device_exp": (u8, [u32, pd, pd]),
     "sf3d_device_cbrt": (u8, [u32, pd, pd]),
+    "sf3d_device_norm_sum": (u8, [u32, pd, u32, i32, pd]),
     "sf3d_get_sweep_launches": (u8, [p64, p64]),
     "sf3d_get_heat_counters": (u8, [p64]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),

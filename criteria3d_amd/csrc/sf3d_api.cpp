@@ -1131,6 +1131,7 @@ sf3d_error_t sf3d_kernel_stats(int k, uint64_t* n, double* ms, uint64_t* nodes) 
 sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out) { return (count && (!x || !out)) ? SF3D_PARAMETER_ERROR : dev().device_log(count, x, out); }
 sf3d_error_t sf3d_device_exp(uint32_t count, const double* x, double* out) { return (count && (!x || !out)) ? SF3D_PARAMETER_ERROR : dev().device_log(count, x, out, 1); }
 sf3d_error_t sf3d_device_cbrt(uint32_t count, const double* x, double* out) { return (count && (!x || !out)) ? SF3D_PARAMETER_ERROR : dev().device_log(count, x, out, 2); }
+sf3d_error_t sf3d_device_norm_sum(uint32_t count, const double* x, uint32_t blocks, int association, double* out) { return ((count && !x) || !out) ? SF3D_PARAMETER_ERROR : dev().device_norm_sum(count, x, blocks, association, out); }
 sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out) { return (count && (!x || !y || !out)) ? SF3D_PARAMETER_ERROR : dev().device_pow(count, x, y, out); }
 
 } /* extern "C" */

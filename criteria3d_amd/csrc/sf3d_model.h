@@ -148,6 +148,7 @@ public:
     static const char* kernel_name(int kid);
     sf3d_error_t device_log(uint32_t n, const double* x, double* out, int which = 0);   /* test hook: the kernels' log (0) / exp (1) / cbrt (2) */
     sf3d_error_t device_pow(uint32_t n, const double* x, const double* y, double* out);   /* test hook: the property kernels' pow */
+    sf3d_error_t device_norm_sum(uint32_t n, const double* x, uint32_t blocks, int assoc, double* out);   /* test hook: the sweep kernels' double-double norm sum */
     uint64_t device_bytes() const;               /* bytes of device memory the model's arrays take (sum of the allocations) */
 
 private:

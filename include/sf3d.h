@@ -373,6 +373,11 @@ sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out);
 sf3d_error_t sf3d_device_exp(uint32_t count, const double* x, double* out);
 /* the same for the cbrt of the runoff links' Manning term (x >= 0) */
 sf3d_error_t sf3d_device_cbrt(uint32_t count, const double* x, double* out);
+/* the norm of a Jacobi sweep (JacobiWaterCPU, water.cpp:592-600: a sum of N terms) as the sweep kernels add it: `count` host terms summed on
+ * the device over `blocks` workgroups in k_sweep's association (0) or the paired passes' (1); out[0] = the double-double sum rounded once
+ * (the same double for every association and block count: tests hold it against an exactly rounded sum), out[1] = the same association
+ * in plain doubles (differs from one association to the next - what the double-double is there for) */
+sf3d_error_t sf3d_device_norm_sum(uint32_t count, const double* x, uint32_t blocks, int association, double* out);
 /* the same for the pow of the soil-property kernels: out[k] = x[k]^y[k], x >= 0 */
 sf3d_error_t sf3d_device_pow(uint32_t count, const double* x, const double* y, double* out);
 

@@ -178,6 +178,7 @@ sf3d_error_t sf3d_kernel_stats(int, uint64_t*, double*, uint64_t*) { return SF3D
 sf3d_error_t sf3d_device_log(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_exp(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_cbrt(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_device_norm_sum(uint32_t, const double*, uint32_t, int, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_get_sweep_launches(uint64_t*, uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_get_heat_counters(uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_pow(uint32_t, const double*, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }

@@ -61,3 +61,34 @@ def test_device_cbrt_equals_host_build(product, fm):  # noqa: F811
         y = np.empty_like(x)
         product.check(product.lib.sf3d_device_cbrt(x.size, x.ctypes.data_as(capi.pd), y.ctypes.data_as(capi.pd)), "device_cbrt")
         assert np.array_equal(y.view(np.int64), fm("fm_cbrt", x).view(np.int64)), name
+
+
+def test_sweep_norm_is_the_exactly_rounded_sum_in_every_association(product):  # noqa: F811
+    """The norm of a Jacobi iteration (water.cpp:592-600) is a sum of N non-negative terms; k_sweep, the paired passes, k_sweep_bnd
+    and the ranks of a sharded run add them in different associations.  As double-doubles (sf3d_physics.inc) every association
+    must round the SAME exact sum once: held here against math.fsum (exactly rounded) for terms of the sizes the solver sees
+    (1e-12 ... 1 per node), for both association shapes and block counts from 1 to 2 048, and for a permuted input.  The plain-double
+    sums of the same associations are reported next to it: they differ from one another, which is why the pair exists."""
+    import math
+    rng = np.random.default_rng(20241003)
+    n = 1 << 20
+    x = np.ascontiguousarray(10.0 ** rng.uniform(-12, 0, n) * rng.uniform(0.5, 1.0, n))
+    x[rng.integers(0, n, n // 8)] = 0.0               # converged nodes
+    exact = math.fsum(x.tolist())
+    plain = set()
+    for terms in (x, np.ascontiguousarray(x[rng.permutation(n)])):
+        for assoc in (0, 1):
+            for blocks in (1, 7, 256, 921, 2048):
+                out = np.zeros(2)
+                product.check(product.lib.sf3d_device_norm_sum(n, terms.ctypes.data_as(capi.pd), blocks, assoc, out.ctypes.data_as(capi.pd)), "device_norm_sum")
+                assert out[0] == exact, (assoc, blocks, out[0], exact)
+                assert abs(out[1] - exact) < 1e-9 * exact
+                plain.add(float(out[1]))
+    assert len(plain) > 1, "the plain-double sums of twenty associations all agree: the contrast leg measures nothing"
+    # the degenerate sizes
+    out = np.zeros(2)
+    product.check(product.lib.sf3d_device_norm_sum(0, None, 4, 0, out.ctypes.data_as(capi.pd)), "device_norm_sum")
+    assert out[0] == 0.0
+    one = np.array([0.1])
+    product.check(product.lib.sf3d_device_norm_sum(1, one.ctypes.data_as(capi.pd), 3, 1, out.ctypes.data_as(capi.pd)), "device_norm_sum")
+    assert out[0] == 0.1
