@@ -464,7 +464,7 @@ def main():
     # cannot collect counters itself
     traffic, traffic_source, run_traffic = None, None, None
     try:
-        for tag in ("r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
+        for tag in ("r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
             f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
             if not f.exists():
                 continue
