@@ -56,16 +56,23 @@ def fullsize_results():
     if not _BACKGROUND:
         pytest.fail("tests/fullsize_worker.py was not started (pytest_collection_finish did not see a fullsize_background test)")
     proc, out = _BACKGROUND["proc"], _BACKGROUND["out"]
+    import time
+    t_wait = time.time()
     try:
         rc = proc.wait(timeout=1500)
     except Exception:
         proc.kill()
         raise
+    t_wait = time.time() - t_wait
     _BACKGROUND["log"].close()
     text = out.with_suffix(".log").read_text()[-3000:]
     assert out.exists(), f"fullsize_worker wrote no results (rc {rc}):\n{text}"
     res = json.loads(out.read_text())
-    res["_rc"], res["_log"] = rc, text
+    res["_rc"], res["_log"], res["_waited_s"] = rc, text, t_wait
+    scratch = os.environ.get("GRAFT_REPO_ROOT")
+    if scratch and os.path.isdir(os.path.join(scratch, "gpurun_out")):      # on the GPU box: how long the suite waited for the worker, and what its parts took
+        with open(os.path.join(scratch, "gpurun_out", "fullsize_worker_times.txt"), "a") as f:
+            f.write(json.dumps({"waited_s": t_wait, **{k: {q: v[q] for q in ("seconds_product", "seconds_total")} for k, v in res.items() if isinstance(v, dict) and "seconds_total" in v}}) + "\n")
     return res
 
 
