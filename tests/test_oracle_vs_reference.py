@@ -39,18 +39,21 @@ def test_thread_count_does_not_change_the_oracles_heat_step(oracle):
     assert m.n >= 4096
     hs = cm.Heat(water=True, latent=True, save_mode=0)
     runs = []
-    for threads in (1, 8, 3):
-        oracle.check(oracle.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(oracle, m, threads=threads, heat=hs)
-        base = oracle.heat_counters()
-        out = []
-        for h, mm in enumerate((5.0, 0.0)):
-            cm.apply_heat_forcing(oracle, m, h)
-            _, dts = cm.run_hour(oracle, m, mm, max_steps=25)
-            out += [np.array(dts), oracle.temperature(0, m.n), oracle.total_potential(0, m.n)]
-        hc = oracle.heat_counters()
-        runs.append((out, {k: hc[k] - base[k] for k in hc}))
-        oracle.lib.sf3d_clean()
+    from tests.scenarios import env
+    # (the level-by-level sweep switches itself on only where a level holds ~1 000 nodes - the whole Ravone project; forced here)
+    for threads, level_gs in ((1, None), (8, "1"), (3, "1"), (8, None)):
+        with env(**({"SF3D_ORACLE_LEVEL_GS": level_gs} if level_gs else {})):
+            oracle.check(oracle.lib.sf3d_reset_solver_state(), "reset")
+            cm.build(oracle, m, threads=threads, heat=hs)
+            base = oracle.heat_counters()
+            out = []
+            for h, mm in enumerate((5.0, 0.0)):
+                cm.apply_heat_forcing(oracle, m, h)
+                _, dts = cm.run_hour(oracle, m, mm, max_steps=25)
+                out += [np.array(dts), oracle.temperature(0, m.n), oracle.total_potential(0, m.n)]
+            hc = oracle.heat_counters()
+            runs.append((out, {k: hc[k] - base[k] for k in hc}))
+            oracle.lib.sf3d_clean()
     for out, work in runs[1:]:
         assert work == runs[0][1], (work, runs[0][1])
         for a, b in zip(out, runs[0][0]):
