@@ -44,3 +44,4 @@ for k in ("k_heat_save_water", "k_heat_assemble", "k_assemble", "k_heat_props", 
     r = res.get(k)
     if r: print(f"{k:26s} waves {r.get('SQ_WAVES',0):9.0f} wait_any {r.get('frac_wait_any',0):.2f} wait_inst {r.get('frac_wait_inst',0):.2f} active {r.get('frac_active_inst',0):.2f} valu {r.get('frac_active_valu',0):.2f} | insts/wave valu {(r.get('SQ_INSTS_VALU') or 0)/max(r.get('SQ_WAVES',1),1):8.0f} trans_f64 {(r.get('SQ_INSTS_VALU_TRANS_F64') or 0)/max(r.get('SQ_WAVES',1),1):6.0f} vmem_rd {(r.get('SQ_INSTS_VMEM_RD') or 0)/max(r.get('SQ_WAVES',1),1):6.0f}")
 PY
+rm -rf $OUT/passA $OUT/passB      # (the raw per-dispatch counter files of an hour of C5 + heat exceed what gpurun copies back)
