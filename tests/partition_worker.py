@@ -191,6 +191,20 @@ def main():
         t = 0.0
         for r in range(world): t += np.abs(new[owner == r] - old[owner == r]).sum()
         return t
+    # the norms as the device adds them since round 4: every partial a double-double (hi = the terms' sum rounded, lo = what that
+    # rounding lost - sf3d_physics.inc "the norm of a Jacobi sweep"), all-gathered with both words, rounded ONCE at the end: the same
+    # double however the nodes are dealt to launches and ranks, i.e. the exactly rounded sum of all terms
+    import math
+    def dd(terms):
+        t = [float(x) for x in terms]
+        hi = math.fsum(t)
+        return hi, math.fsum(t + [-hi])
+    def allsum_dd(*pairs):
+        parts = [None] * world
+        dist.all_gather_object(parts, [w for p in pairs for w in p])
+        return math.fsum(w for r in range(world) for w in parts[r])
+    def gnorm_exact(new, old):
+        return math.fsum(np.abs(new - old).tolist())
     everyone = np.arange(len(mine))
     for approx, niter in enumerate((6, 5, 1, 4)):
         it = 0
@@ -211,8 +225,11 @@ def main():
                 n2_inner = np.abs(x2[mine[inner]] - x1[mine[inner]]).sum()
                 put(0, lambda p: x1[send[p]])
                 n1t, n2t = allsum(n1), allsum(n2_inner)
+                n1dd = allsum_dd(dd(np.abs(x1[mine] - xs[mine])))
+                dd_inner = dd(np.abs(x2[mine[inner]] - x1[mine[inner]]))
                 dist.barrier(); epoch += 1
                 assert n1t == n1g and np.array_equal(x1[mine], g1[mine]), f"paired sweep, approximation {approx} iteration {it}: x'"
+                assert n1dd == gnorm_exact(g1, xg), "first norm as double-doubles: the exactly rounded sum, whatever the partition"
                 # launch 2: the nodes next to the neighbours, x' of the neighbours from the window
                 edge = np.flatnonzero(in_bnd)
                 x2[mine[edge]] = sweep_rows(edge, x1, True)
@@ -220,9 +237,11 @@ def main():
                 xs[mine] = x2[mine]
                 put(0, lambda p: xs[send[p]])
                 n2t = n2t + allsum(n2_edge)
+                n2dd = allsum_dd(dd_inner, dd(np.abs(x2[mine[edge]] - x1[mine[edge]])))      # (k_sweep_bnd adds the part the pass left in Ctrl::pairNorm2 / pairNorm2Lo)
                 dist.barrier(); epoch += 1
                 assert np.array_equal(xs[mine], g2[mine]), f"paired sweep, approximation {approx} iteration {it}: x''"
-                assert abs(n2t - n2g) <= 4e-16 * n2g       # (the second norm is the same terms in another association: inner + edge)
+                assert abs(n2t - n2g) <= 4e-16 * n2g       # (plain doubles: the second norm is the same terms in another association - inner + edge)
+                assert n2dd == gnorm_exact(g2, g1), "second norm as double-doubles: inner + edge parts of every rank round to the global sum"
                 xg = g2; it += 2
             else:                                         # the odd iteration: a single sweep
                 g1 = jacobi_rows(np.arange(m.n), A, J, b, xg)
