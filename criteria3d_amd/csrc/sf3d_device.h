@@ -223,7 +223,7 @@ struct HeatDev {
     uint32_t gs;                                    /* 1: verification mode, the reference's serial Gauss-Seidel order (level-scheduled) */
     uint32_t redBlack;                              /* 1 (default): the heat sweep is a Gauss-Seidel sweep in two colours, odd layers then even layers; 0: Jacobi (SF3D_HEAT_SWEEP=jacobi) */
     const uint8_t* lpar;                            /* [N] layer of the node (hops to the surface through Up links), low bit = its colour */
-    const uint32_t* colourList[2]; uint32_t nColour[2];   /* chunks that hold a node of an odd layer [0] / of an even layer [1] (one GPU; in list order) */
+    const uint32_t* colourList[2]; uint32_t nColour[2];   /* chunks that hold a node of an odd layer [0] / of an even layer [1], in list order (sharded runs: plus the chunks that owe values to a neighbour, in both) */
     const uint32_t* gsOrder;                        /* heat nodes sorted by dependency level (gs mode only) */
     double wf;                                      /* heatWeightFactor, types.h:307 */
     double* TX[3];                                  /* temperature pool: T, Told and the sweep buffers are indices (Ctrl::tCur/tOld) */
