@@ -64,8 +64,8 @@ def compare(g, o):
     return res
 
 
-def water(product, results):
-    """see tests/test_gpu_ravone_project.py::test_project_full_size_runoff_regime_matches_oracle"""
+def water_product(product):
+    """the product's runs of tests/test_gpu_ravone_project.py::test_project_full_size_runoff_regime_matches_oracle"""
     m = ravone_project_model(None)
     t0 = time.time()
     product.check(product.lib.sf3d_reset_solver_state(), "reset")
@@ -78,7 +78,12 @@ def water(product, results):
     H1, dt1 = product.total_potential(0, m.n), product.lib.sf3d_get_time_step()
     late, = segment(product, m, H1, dt1, 100)
     product.lib.sf3d_clean()
-    t_gpu = time.time() - t0
+    return dict(m=m, n0=n0, warm=warm, H0=H0, dt0=dt0, H1=H1, dt1=dt1, g50=g50, g300=g300, late=late, t0=t0, t_gpu=time.time() - t0)
+
+
+def water_checkers(p, results):
+    m, H0, dt0, H1, dt1 = p["m"], p["H0"], p["dt0"], p["H1"], p["dt1"]
+    t0 = time.time()
     oracle, twin, second = checkers.load_oracle(), checkers.load_oracle_fastmath(), checkers.load_oracle_copy("second")
     with ThreadPoolExecutor(3) as pool:          # (ctypes calls release the interpreter lock)
         j_twin = pool.submit(segment, twin, m, H0, dt0, 300, 6)
@@ -87,30 +92,47 @@ def water(product, results):
         o50, = j_pin.result(); o_late, = j_late.result(); t300, = j_twin.result()
     for sf in (oracle, twin, second):
         sf.lib.sf3d_clean()
-    results["water"] = {"nodes": int(m.n), "surface_nodes": int(m.ns), "hour0_steps": int(n0), "hour0_courant_rejections": int(warm["courant_rejections"]),
+    results["water"] = {"nodes": int(m.n), "surface_nodes": int(m.ns), "hour0_steps": int(p["n0"]), "hour0_courant_rejections": int(p["warm"]["courant_rejections"]),
                         "finite": bool(np.all(np.isfinite(H0)) and np.all(np.isfinite(H1))),
-                        "pin": compare(g50, o50), "twin": compare(g300, t300), "late": compare(late, o_late),
-                        "seconds_product": t_gpu, "seconds_total": time.time() - t0}
+                        "pin": compare(p["g50"], o50), "twin": compare(p["g300"], t300), "late": compare(p["late"], o_late),
+                        "seconds_product": p["t_gpu"], "seconds_total": p["t_gpu"] + time.time() - t0}
 
 
-def heat(product, results):
-    """see tests/test_gpu_heat.py::test_heat_project_full_size_fifty_steps"""
+HEAT = cm.Heat(water=True, latent=True, save_mode=0)
+
+
+def heat_product(product):
+    """the product's runs of tests/test_gpu_heat.py::test_heat_project_full_size_fifty_steps"""
     m = cm.with_heat_surface(ravone_project_model(None))
-    hs = cm.Heat(water=True, latent=True, save_mode=0)
     t0 = time.time()
     product.check(product.lib.sf3d_reset_solver_state(), "reset")
-    cm.build(product, m, heat=hs)
+    cm.build(product, m, heat=HEAT)
     cm.apply_heat_forcing(product, m, 0)
     n0, _ = cm.run_hour(product, m, 20.0)
     H0, T0, dt0 = product.total_potential(0, m.n), product.temperature(0, m.n), product.lib.sf3d_get_time_step()
-    g, = segment(product, m, H0, dt0, 50, heat=hs, T0=T0)
+    g, = segment(product, m, H0, dt0, 50, heat=HEAT, T0=T0)
     product.lib.sf3d_clean()
-    t_gpu = time.time() - t0
+    return dict(m=m, n0=n0, H0=H0, T0=T0, dt0=dt0, g=g, t_gpu=time.time() - t0)
+
+
+def heat_checker(p, results):
+    m, H0, T0 = p["m"], p["H0"], p["T0"]
+    t0 = time.time()
     oracle = checkers.load_oracle()
-    o, = segment(oracle, m, H0, dt0, 50, threads=12, heat=hs, T0=T0)
+    o, = segment(oracle, m, H0, p["dt0"], 50, threads=12, heat=HEAT, T0=T0)
     oracle.lib.sf3d_clean()
-    results["heat"] = {"nodes": int(m.n), "hour0_steps": int(n0), "finite": bool(np.all(np.isfinite(H0)) and np.all(np.isfinite(T0[m.ns:]))),
-                       "fifty": compare(g, o), "seconds_product": t_gpu, "seconds_total": time.time() - t0}
+    results["heat"] = {"nodes": int(m.n), "hour0_steps": int(p["n0"]), "finite": bool(np.all(np.isfinite(H0)) and np.all(np.isfinite(T0[m.ns:]))),
+                       "fifty": compare(p["g"], o), "seconds_product": p["t_gpu"], "seconds_total": p["t_gpu"] + time.time() - t0}
+
+
+def release_gpu():
+    """The product's runs are done: give the device back (context, queues, streams) - minutes of checker time follow, during which
+    the suite's multi-rank tests start several GPU processes of their own on the same device."""
+    import ctypes
+    try:
+        ctypes.CDLL("libamdhip64.so").hipDeviceReset()
+    except OSError:
+        pass
 
 
 def main():
@@ -119,13 +141,23 @@ def main():
     product = capi.load_product()
     results = {}
     try:
-        if "water" in parts:
-            water(product, results)
-        if "heat" in parts:
-            heat(product, results)
+        # every product run first (under a minute of GPU time in all, at the start of the suite), then the GPU is released and the
+        # checkers take their minutes of CPU time
+        pw = water_product(product) if "water" in parts else None
+        ph = heat_product(product) if "heat" in parts else None
+        del product
+        release_gpu()
+        if pw is not None:
+            water_checkers(pw, results)
+            out.write_text(json.dumps(results))
+        if ph is not None:
+            heat_checker(ph, results)
     finally:
         out.write_text(json.dumps(results))          # what was finished is reported even if a later part fails
 
 
 if __name__ == "__main__":
     main()
+    sys.stdout.flush(); sys.stderr.flush()
+    import os
+    os._exit(0)          # (the device was reset under the product library: skip its static destructors)

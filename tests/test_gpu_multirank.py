@@ -16,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 RTOL = 1e-6
 
 
-def run_ranks(world, case, tmp_path, port, env=None):
+def _run_ranks_once(world, case, tmp_path, port, env):
     import os
     procs, outs = [], []
     for r in range(world):
@@ -24,7 +24,7 @@ def run_ranks(world, case, tmp_path, port, env=None):
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), str(world),
                                        str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                                      env=dict(os.environ, **(env or {}))))
+                                      env=dict(os.environ, SF3D_DIST_VERBOSE="1", **(env or {}))))
     logs = []
     for p in procs:
         try:
@@ -34,7 +34,23 @@ def run_ranks(world, case, tmp_path, port, env=None):
                 q.kill()
             raise
         logs.append(o)
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return all(p.returncode == 0 for p in procs), logs, outs
+
+
+SETUP_FAILURES = ("did not answer within the bounded wait", "no answer from rank", "no answer through the window", "self-check kernel failed")
+
+
+def run_ranks(world, case, tmp_path, port, env=None):
+    """`world` rank processes sharing the one GPU of the box.  Several processes' spinning kernels on one device depend on the
+    hardware scheduler running them side by side; once in a dozen suite runs (round 4, job 33: the first contact of a 2-rank case
+    while other GPU processes of the suite were alive) a rank's start-up self-check timed out.  That is the box, not the exchange
+    (one process per GPU is the product's layout): such a SET-UP failure is retried once, loudly; anything else fails at once."""
+    ok, logs, outs = _run_ranks_once(world, case, tmp_path, port, env)
+    if not ok and any(k in log for log in logs for k in SETUP_FAILURES):
+        import warnings
+        warnings.warn(f"multi-rank case {case} x{world}: exchange set-up failed on the shared GPU, retrying once:\n" + "\n".join(l[-1500:] for l in logs))
+        ok, logs, outs = _run_ranks_once(world, case, tmp_path, port + 400, env)
+    assert ok, "\n".join(logs)
     return [np.load(o) for o in outs]
 
 
