@@ -72,7 +72,23 @@ def test_bench_runs_and_prints_one_json_line():
     assert line["config"]["work"]["accepted"] == 22          # C2 F20 hour 0
 
 
+def _run_shared_gpu_bench(cmd, env):
+    """bench.py with its ranks on the ONE GPU of the test box.  Several processes' spinning kernels on one device depend on the hardware
+    scheduler running them side by side (tests/test_gpu_multirank.py::run_ranks): a SET-UP time-out (exit code 4, "strips not
+    connected") is retried once, loudly; any other failure is final."""
+    import subprocess
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    if p.returncode == 4 and "strips not connected" in p.stderr and "SF3D_BENCH_FORCE_REPLICAS" not in env:
+        import warnings
+        warnings.warn("bench.py: the ranks sharing the GPU could not connect their strips, retrying once:\n" + p.stderr[-1500:])
+        if "--master-port" in cmd:
+            cmd = list(cmd); cmd[cmd.index("--master-port") + 1] = str(int(cmd[cmd.index("--master-port") + 1]) + 400)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    return p
+
+
 @pytest.mark.gpu
+@pytest.mark.gpu_timing          # (rank processes of its own on the shared GPU: after the background worker's product runs, like the timing tests)
 def test_bench_two_ranks_sharing_the_gpu():
     """the launch the driver uses for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with both ranks on the
     one GPU of the test box (SF3D_BENCH_SHARE_GPU=1: gloo control plane, same device-side exchange)"""
@@ -80,9 +96,9 @@ def test_bench_two_ranks_sharing_the_gpu():
     import subprocess
     import sys
     env = dict(os.environ, SF3D_BENCH_SHARE_GPU="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "1", "--warmup", "0",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    p = _run_shared_gpu_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                               "--master-port", "29631", str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "1", "--warmup", "0",
+                               "--no-cpu-baseline"], env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
@@ -97,6 +113,7 @@ def test_bench_two_ranks_sharing_the_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.gpu_timing
 def test_bench_spawns_its_own_ranks():
     """`python bench.py --gpus 2` with NO launcher - how the driver calls it - starts two fresh rank processes itself, relays rank
     0's line and carries the self-describing fields (driver-timed 6-hour headline, repetitions, inclusive rate, traffic source)"""
@@ -105,8 +122,8 @@ def test_bench_spawns_its_own_ranks():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["SF3D_BENCH_SHARE_GPU"] = "1"
-    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "6", "--warmup", "0", "--reps", "2",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    p = _run_shared_gpu_bench([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "C2", "--steps", "6", "--warmup", "0", "--reps", "2",
+                               "--no-cpu-baseline"], env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
