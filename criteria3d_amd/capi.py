@@ -137,6 +137,7 @@ SIGNATURES = {
     "sf3d_kernel_count": (i32, []),
     "sf3d_kernel_name": (cstr, [i32]),
     "sf3d_kernel_stats": (u8, [i32, p64, pd, p64]),
+    "sf3d_libm_set": (i32, []),
     "sf3d_device_log": (u8, [u32, pd, pd]),
     "sf3d_device_exp": (u8, [u32, pd, pd]),
     "sf3d_device_cbrt": (u8, [u32, pd, pd]),

@@ -366,6 +366,10 @@ const char*  sf3d_kernel_name(int k);
 /* launches, total milliseconds and nodes processed per launch of kernel k since timing was
  * enabled (drains the event pool) */
 sf3d_error_t sf3d_kernel_stats(int k, uint64_t* launches, double* total_ms, uint64_t* nodes_per_launch);
+/* Which elementary functions (log / exp / pow / cbrt) the kernels evaluate: 1 = the operations of the reference build's C library
+ * (glibc 2.35: soilPhysics.cpp:68-279, otherFunctions.cpp:35, water.cpp:389-469, heat.cpp:702-845 call it), bit for bit - the default build;
+ * 0 = the library's own 0.50-ulp table routines of earlier rounds (a build option, -DSF3D_LIBM_GLIBC=0: DESIGN.md 4). */
+int sf3d_libm_set(void);
 /* Test hooks: the logarithm the link kernels use for the logarithmic mean (a table-driven routine) evaluated on
  * the device for `count` host values; tests compare it bit for bit with the host build of the same source. */
 sf3d_error_t sf3d_device_log(uint32_t count, const double* x, double* out);

@@ -175,6 +175,7 @@ sf3d_error_t sf3d_kernel_timing(int) { return SF3D_MISSING_DATA_ERROR; }
 int sf3d_kernel_count(void) { return 0; }
 const char* sf3d_kernel_name(int) { return nullptr; }
 sf3d_error_t sf3d_kernel_stats(int, uint64_t*, double*, uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
+int sf3d_libm_set(void) { return 1; }      /* the reference calls the C library */
 sf3d_error_t sf3d_device_log(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_exp(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_cbrt(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }

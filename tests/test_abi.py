@@ -87,6 +87,35 @@ def fresh(sf, n=6, ns=2):
 
 
 @pytest.mark.parametrize("which", ["product", "oracle"])
+@pytest.mark.parametrize("order", ["many soils first", "one soil first"])
+def test_soil_index_table_outlives_reinitialisation(which, order, request):
+    """Two models in one process, in both orders.  The reference never clears its (soil, horizon) -> soil-list index table
+    (soil1DIndices, soilFluxes3D.cpp:39) while cleanSF3D / initializeSF3D start a new soil list: after a model with twelve soils, a
+    model with one soil still finds an entry for soil 5 - pointing past the new list.  The reference stores the address of that
+    element (soilFluxes3D.cpp:745-748: undefined behaviour); product and oracle both answer ParameterError and stay usable.  (Round 4's
+    review: the oracle stored the stale index - a latent out-of-bounds read in the checker that only one order of the test files hit.)"""
+    sf = request.getfixturevalue(which)
+    L = sf.lib
+    soil = lambda k: (k, 0, 3.6, 1.56, 1 - 1 / 1.56, 0.1, 0.078, 0.43, 2.9e-6, 0.5, 0.01, 0.2)      # noqa: E731
+
+    def model(n_soils):
+        fresh(sf)
+        for k in range(n_soils):
+            assert L.sf3d_set_soil_properties(*soil(k)) == capi.OK
+        for i in range(6):
+            assert L.sf3d_set_node(i, float(i), 0, 1.0 if i < 2 else 0.5, 1.0, 1 if i < 2 else 0, 0, 0, 0) == capi.OK
+        assert L.sf3d_set_node_soil(2, 0, 0) == capi.OK
+        want = capi.OK if n_soils > 5 else capi.PARAMETER_ERROR
+        assert L.sf3d_set_node_soil(3, 5, 0) == want, (n_soils, order)
+        assert L.sf3d_set_node_soil(3, 40, 0) == capi.PARAMETER_ERROR
+        assert L.sf3d_set_node_soil(3, 0, 0) == capi.OK          # still usable after the refusal
+        L.sf3d_clean()
+
+    for n in ((12, 1, 12) if order == "many soils first" else (1, 12, 1)):
+        model(n)
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
 def test_validation_rules_match_reference(which, request):
     sf = request.getfixturevalue(which)
     L = sf.lib
