@@ -366,8 +366,8 @@ def main():
                 log(f"[bench] rank {rank}: the multi-GPU exchange could not be set up; no line is printed "
                     "(SF3D_BENCH_ALLOW_REPLICAS=1 runs labelled independent replicas instead)")
                 sf.lib.sf3d_clean()
-                dist.barrier()
-                dist.destroy_process_group()
+                # (no collective here: a peer that died instead of reporting would leave this rank in the barrier for good; the launcher
+                # collects the exit codes)
                 sys.exit(4)
             replicas = whys[0][:300]
             log(f"[bench] rank {rank}: SF3D_BENCH_ALLOW_REPLICAS=1: running {world} independent replicas instead")
@@ -432,6 +432,21 @@ def main():
         raise RuntimeError(f"rank {rank}: the state is not finite after the timed steps (total water content {tw}): invalid run")
     sf.lib.sf3d_kernel_timing(0)
 
+    exchange = None
+    if world > 1 and shard is not None:
+        # every rank: which transport carried the run and what an exchange cost it - the numbers a first contact with real GPUs is read by
+        # (one stderr line per rank; rank 0's also goes on the JSON line)
+        try:
+            st = sf.dist_stats(world)
+            tname = {0: "none", 1: "HIP-IPC device windows", 2: "host-memory windows", 3: "RCCL"}.get(int(sf.lib.sf3d_dist_transport()), "?")
+            peers = {p: v for p, v in st["peers"].items() if p != rank}
+            exchange = {"transport": tname, "epochs": st["epochs"], "hop_us": {str(p): v["hop_us"] for p, v in peers.items()},
+                        "mean_wait_us": {str(p): v["mean_wait_us"] for p, v in peers.items()}, "max_wait_us": {str(p): v["max_wait_us"] for p, v in peers.items()}}
+            log(f"[bench] rank {rank}: exchange transport {tname}; " + "; ".join(
+                f"peer {p}: hop {v['hop_us']:.2f} us, wait per epoch mean {v['mean_wait_us']:.2f} us max {v['max_wait_us']:.1f} us" for p, v in peers.items())
+                + f"; {st['epochs']} exchange epochs")
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] rank {rank}: exchange statistics unavailable: {e}")
     if rank != 0:
         sf.lib.sf3d_clean()
         if world > 1:
@@ -560,6 +575,8 @@ def main():
         "value_timing": f"median of {reps} repetitions of the timed region; repetition 0 carries the HIP-event sampling of the dominant kernel "
                         f"(every 8th computeStep launched eagerly), the others replay hipGraphs uninstrumented; repetition 0 took {rep_elapsed[0]:.4f} s",
         "f60_hour0": f60,
+        "exchange": exchange,          # N > 1: rank 0's transport, flag-hop latency to every peer and wait per exchange epoch (every rank prints its own on stderr)
+        "metric_definition": "v2 (round 4 on): `value` = 6 simulated hours / median complete 6-hour episode whatever --steps is (K < 6: K hours / their time); rounds 1-3: K hours / their time - see `timed_region` for that figure",
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

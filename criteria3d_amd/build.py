@@ -144,10 +144,25 @@ def build_oracle(with_reference: bool = True) -> None:
         _run(["make", "-C", str(ROOT / "oracle"), "ref-ndebug"])
 
 
+RCCL_MOCK = ROOT / "tests" / "librccl_mock.so"
+
+
+def build_rccl_mock(force: bool = False) -> Path:
+    """Test infrastructure (tests/rccl_mock.cpp): the nine RCCL entry points the opt-in RCCL exchange resolves, carried by shared
+    memory, so that its sequencing runs with the ranks of a test sharing one GPU.  Host code only: g++ against the HIP runtime."""
+    src = ROOT / "tests" / "rccl_mock.cpp"
+    rocm = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+    if force or _stale(RCCL_MOCK, [src]):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", f"-I{rocm / 'include'}", str(src), "-o", str(RCCL_MOCK),
+              f"-L{rocm / 'lib'}", "-lamdhip64", "-lrt", "-lpthread", f"-Wl,-rpath,{rocm / 'lib'}"])
+    return RCCL_MOCK
+
+
 def build_all(force: bool = False) -> None:
     build_product(force)
     build_shim(force)
     build_v1_alias(force)
     build_v2_demo(force)
     build_static_dropin(force)
+    build_rccl_mock(force)
     build_oracle()

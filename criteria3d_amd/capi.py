@@ -154,6 +154,7 @@ SIGNATURES = {
     "sf3d_dist_status": (i32, []),
     "sf3d_dist_finalize": (u8, [i32]),
     "sf3d_dist_transport": (i32, []),
+    "sf3d_dist_stats": (u8, [pd, i32]),
     "sf3d_get_regular_grid": (u8, [p32, p32, p32, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
     "sf3d_dist_owner": (u8, [i32, u32, u32, C.POINTER(C.c_int32)]),
     "sf3d_dist_halo": (u8, [i32, i32, i32, i32, u32, p32, p32]),
@@ -326,6 +327,13 @@ class SF3D:
         failed = any(b[0] for b in status)
         mode = 0 if not failed else (1 if os.environ.get("SF3D_EXCHANGE") == "rccl" else 2)
         self.check(self.lib.sf3d_dist_finalize(mode), "dist_finalize")
+
+    def dist_stats(self, world):
+        """{"epochs": n, "peers": {p: {"hop_us", "mean_wait_us", "max_wait_us"}}} of a connected multi-rank model"""
+        out = np.zeros(1 + 3 * world)
+        self.check(self.lib.sf3d_dist_stats(out.ctypes.data_as(pd), out.size), "dist_stats")
+        return {"epochs": int(out[0]), "peers": {p: {"hop_us": float(out[1 + 3 * p]), "mean_wait_us": float(out[2 + 3 * p]), "max_wait_us": float(out[3 + 3 * p])}
+                                                 for p in range(world)}}
 
     def owner_map(self, world, n):
         out = np.empty(n, dtype=np.int32)

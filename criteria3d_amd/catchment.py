@@ -171,7 +171,10 @@ def catchment_model(nx: int, ny: int, nz: int, heterogeneous: bool = False, cell
                  is_surface=(l == 0).astype(np.uint8), btype=btype, bslope=bslope, barea=barea,
                  link_node=link_node, link_to=link_to, link_dir=link_dir, link_area=link_area,
                  soil_index=soil_index, soils=soils, numerics=(min(6.0, cell / 20.0), 3600.0, 150, 10, 10, 3),
-                 cell_area=area, shape=(nx, ny, nz), meta=dict(kind="catchment", heterogeneous=heterogeneous))
+                 cell_area=area, shape=(nx, ny, nz),
+                 # layers / index / cell: what criteria3d_amd/esri.py needs to write and read the application's WP_<depth cm>.flt state directory
+                 meta=dict(kind="catchment", heterogeneous=heterogeneous, layers=[thickness] * (nz - 1), cell=cell,
+                           index=np.arange(n, dtype=np.int64).reshape(nz, ny, nx)))
 
 
 @dataclass
@@ -210,6 +213,38 @@ def with_heat_surface(m: Model) -> Model:
     m.bslope[top] = 0.0
     m.barea[top] = m.cell_area
     return m
+
+
+def renumber_soil_nodes(m: Model, new_of_old: np.ndarray) -> Model:
+    """copy of the model with its SOIL nodes renumbered (surface nodes keep [0, ns): the library requires that):
+    `new_of_old[k]` = new index of soil node ns + k, a permutation of ns .. n - 1.  Links keep their order (a node's k-th lateral stays
+    its k-th lateral), so sums over a row's links are taken in the same order as before."""
+    import copy
+    m = copy.deepcopy(m)
+    mp = np.arange(m.n)
+    mp[m.ns:] = np.asarray(new_of_old)
+    assert np.array_equal(np.sort(mp), np.arange(m.n))
+    inv = np.empty(m.n, dtype=np.int64)
+    inv[mp] = np.arange(m.n)
+    for name in ("x", "y", "z", "size", "is_surface", "btype", "bslope", "barea"):
+        setattr(m, name, np.ascontiguousarray(getattr(m, name)[inv]))
+    m.soil_index = np.ascontiguousarray(m.soil_index[inv[m.ns:] - m.ns])
+    if m.horizon_index is not None:
+        m.horizon_index = np.ascontiguousarray(m.horizon_index[inv[m.ns:] - m.ns])
+    m.link_node = mp[m.link_node].astype(m.link_node.dtype)
+    m.link_to = mp[m.link_to].astype(m.link_to.dtype)
+    return m
+
+
+def bottom_up(m: Model) -> Model:
+    """the same layered model with its soil layers numbered from the BOTTOM up (every Up neighbour of a soil node below the first
+    layer has the larger index): a numbering the API accepts and the reference's serial sweeps handle like any other"""
+    ncol = m.ns
+    nl = (m.n - m.ns) // ncol
+    assert m.ns + nl * ncol == m.n, "needs whole layers"
+    k = np.arange(m.n - m.ns)
+    layer, col = k // ncol, k % ncol
+    return renumber_soil_nodes(m, m.ns + (nl - 1 - layer) * ncol + col)
 
 
 def heat_forcing(h: int) -> dict:

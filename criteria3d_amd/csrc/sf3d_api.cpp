@@ -176,6 +176,7 @@ sf3d_error_t buildLocal()
     L.N = (uint32_t)LM.l2g.size();
     L.ns = 0; for (uint32_t g : LM.l2g) if (g < M.ns) ++L.ns;
     L.globalN = M.N;
+    L.heatTwoColour = (M.heat && heat_two_colour_valid(M)) ? 1 : 0;      /* decided on the global graph: the same answer on every rank */
     gatherTo(L.x, M.x); gatherTo(L.y, M.y); gatherTo(L.z, M.z); gatherTo(L.size, M.size); gatherTo(L.surf, M.surf);
     gatherTo(L.hasClass, M.hasClass); gatherTo(L.cls, M.cls); gatherTo(L.btype, M.btype); gatherTo(L.bslope, M.bslope); gatherTo(L.bsize, M.bsize);
     gatherTo(L.bflowRate, M.bflowRate); gatherTo(L.bflowSum, M.bflowSum); gatherTo(L.prescribed, M.prescribed); gatherTo(L.nLat, M.nLat);
@@ -1027,6 +1028,7 @@ sf3d_error_t sf3d_dist_finalize(int mode)
     return e;
 }
 int sf3d_dist_transport(void) { return dev().dist_transport(); }
+sf3d_error_t sf3d_dist_stats(double* out, int capacity) { return out ? dev().dist_stats(out, capacity) : SF3D_PARAMETER_ERROR; }
 uint64_t sf3d_host_bytes(void)
 {
     uint64_t n = 0;

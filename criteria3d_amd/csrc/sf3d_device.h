@@ -207,6 +207,10 @@ struct DistView {
     const double* gathered;              /* [world][3] after ncclAllGather */
     double* sendBuf[SF3D_MAX_RANKS];     /* per peer: [2 fields][sendCount] packed halo values */
     const double* recvBuf[SF3D_MAX_RANKS];
+    /* wait statistics of the window exchange (device memory of this rank, zeroed at connect): [0] epochs closed, [1 + p] ticks (100 MHz)
+     * spent waiting for rank p's mailbox, summed over the epochs, [1 + SF3D_MAX_RANKS + p] the longest single wait - what a rank loses
+     * per exchange to the slowest of its peers (sf3d_dist_stats; bench.py prints it per rank) */
+    unsigned long long* stats;
 };
 /* payload layout per (receiver, source p): [parity 0/1][field][count] doubles at offset off[p];
  * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate

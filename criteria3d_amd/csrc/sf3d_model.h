@@ -71,10 +71,32 @@ struct HostModel {
      * GLOBAL node count */
     const struct Partition* presetPartition = nullptr;
     uint32_t globalN = 0;                       /* 0: this IS the global model */
+    int heatTwoColour = -1;                     /* strip-local model: whether the GLOBAL graph admits the two-colour heat sweep (heat_two_colour_valid below; every rank
+                                                 * must take the same decision); -1: decide on this model */
     /* what the host lacks (device is newer) */
     bool hostStaleState = false; /* H, Se, K                                                      */
     bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */
 };
+
+/* The two-colour heat sweep (sf3d_heat.inc: odd layers from the old iterate, then even layers with their Up / Down neighbours taken
+ * from the values the first half has just written) is a valid, deterministic Gauss-Seidel ordering only if "layer parity" colours the
+ * vertical links: layer = hops to the surface through the Up links, defined where the node above has the SMALLER index (layer-major
+ * numbering), and every Up / Down link must join nodes of opposite parity.  A numbering the API accepts but this does not hold for
+ * (bottom-up columns, a Down link whose target's Up is another node) would make the second half read same-colour values that the
+ * same launch is writing - a race (round 4's advice).  Such graphs keep the Jacobi sweep. */
+inline bool heat_two_colour_valid(const HostModel& m)
+{
+    std::vector<uint8_t> lp(m.N, 0);
+    for (uint32_t i = m.ns; i < m.N; ++i)
+        if (m.ltype[0][i] != SF3D_LINK_NONE) {
+            if (m.lto[0][i] >= i) return false;
+            lp[i] = (uint8_t)(lp[m.lto[0][i]] + 1);
+        }
+    for (uint32_t i = m.ns; i < m.N; ++i)
+        for (int s = 0; s < 2; ++s)
+            if (m.ltype[s][i] != SF3D_LINK_NONE && ((lp[i] ^ lp[m.lto[s][i]]) & 1u) == 0u) return false;
+    return true;
+}
 
 /* Row-strip partition of the node graph for `world` ranks (host logic, no device needed):
  * a node belongs to the rank that owns its surface-cell column (the surface node reached by
@@ -139,6 +161,8 @@ public:
     sf3d_error_t dist_connect(const DistBlob* all);
     int dist_status() const { return distStatus_; }
     int dist_transport() const;
+    sf3d_error_t dist_stats(double* out, int capacity);
+    void print_hops() const;
     sf3d_error_t dist_finalize(int mode);      /* 0 device windows (all ranks passed), 1 RCCL (opt-in), 2 host-memory windows (fall-back) */
     int world() const { return world_; }
     int rank() const { return rank_; }

@@ -413,12 +413,20 @@ sf3d_error_t sf3d_dist_connect(const void* blobs_of_all_ranks);
  *           shared-memory copy of its window in its blob; all ranks map and register them (hipHostRegister) and repeat the self-check
  *           through them.  Slower (both ends of an exchange cross PCIe), same protocol, same bits.  SF3D_EXCHANGE=host forces it;
  *   mode 1  only with SF3D_EXCHANGE=rccl: all ranks join the communicator whose id rank 0 put into its blob (collective:
- *           ncclCommInitRank) and move halos with ncclSend/ncclRecv and the partial sums with ncclAllGather (coded, not yet run on
- *           hardware); without that opt-in mode 1 is an error on every rank. */
+ *           ncclCommInitRank) and move halos with ncclSend/ncclRecv and the partial sums with ncclAllGather (its sequencing runs
+ *           in the tests over a shared-memory stand-in for librccl, SF3D_RCCL_LIB; never between two physical GPUs yet);
+ *           without that opt-in mode 1 is an error on every rank. */
 int          sf3d_dist_status(void);
 sf3d_error_t sf3d_dist_finalize(int mode);
 /* which exchange a connected multi-rank model uses: 0 none (one rank, or not connected), 1 device windows, 2 host-memory windows, 3 RCCL */
 int          sf3d_dist_transport(void);
+/* What the window exchange costs this rank (a connected multi-rank model; diagnostics for a first contact between real GPUs - bench.py
+ * prints it per rank): out[0] = exchange epochs closed since the connect (one per Jacobi iteration, halo of K / waterFlow, balance ...);
+ * for every rank p: out[1 + 3 p] = flag-hop latency to rank p measured at sf3d_dist_finalize [us] (a system-scope store into p's window
+ * seen by p's polling load, handed back and forth 256 times; 0 for the own rank and for the RCCL transport), out[2 + 3 p] = mean wait
+ * for rank p's mailbox per epoch [us] (hop + how far p runs behind), out[3 + 3 p] = the longest single wait [us].
+ * capacity >= 1 + 3 * world doubles, else SF3D_MEMORY_ERROR; SF3D_MISSING_DATA_ERROR without a connected multi-rank model. */
+sf3d_error_t sf3d_dist_stats(double* out, int capacity);
 /* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
 /* Host logic, no device needed: SF3D_OK and the shape if the staged node graph is a regular NX x NY x NZ grid in layer-major
  * numbering i = (l NY + r) NX + c with the ten-link stencil (slot 0 up, 1 down, laterals to the 8-neighbourhood of the layer;

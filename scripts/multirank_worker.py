@@ -20,6 +20,9 @@ def allgather(b):
 sf = capi.load_product()
 if case.endswith("_nofinalize"):
     sf.legacy_connect = True; case = case[:-len("_nofinalize")]
+edit_after = case.endswith("_editafter")
+if edit_after:
+    case = case[:-len("_editafter")]
 sf.check(sf.lib.sf3d_set_device(int(os.environ.get("SF3D_TEST_DEVICE", "0"))), "set_device")
 if case == "c2f20":
     m, plan = cm.catchment_model(64, 64, 10), [20.0, 0.0]
@@ -53,6 +56,17 @@ if case not in ("ravone", "c4f20h0"):
     cm.run_hour(sf, m, 5.0, max_steps=2)
     sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
+if edit_after:
+    # a graph-dirtying setter AFTER connect / finalize (the strip's build arrays are trimmed by then): every rank must get the
+    # documented TopographyError from the next device call - no crash, no peer left in a time-out - and a NaN from computeStep
+    cm.run_hour(sf, m, 5.0, max_steps=2)
+    codes = {"set": int(sf.lib.sf3d_set_surface_properties(0, 0.05)), "balance": int(sf.lib.sf3d_initialize_balance())}
+    dt = float(sf.lib.sf3d_compute_step(10.0))
+    np.savez(outfile, set=np.array(codes["set"]), balance=np.array(codes["balance"]), dt=np.array(dt))
+    dist.barrier()
+    sf.lib.sf3d_clean()
+    dist.destroy_process_group()
+    sys.exit(0)
 owner = sf.owner_map(world, m.n)
 res = {"owner": owner, "transport": np.array(int(sf.lib.sf3d_dist_transport())), "host_bytes": np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)}      # the library's resident staging memory once connected
 t0 = time.time()

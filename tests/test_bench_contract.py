@@ -110,6 +110,16 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert r["kernel"] == "k_sweep" and r["algorithmic_bytes_per_launch"] == 152 * 20480, r
     assert abs(r["achieved"] - 152 * 20480 / (r["avg_us"] * 1e-6) / 1e9) < 1e-9 * r["achieved"]
     assert "exchange HIP-IPC windows - windows passed the self-check" in p.stderr and "SAME GPU" in p.stderr      # every rank says which exchange came up
+    # ... and what it cost: transport, flag-hop latency to the peer, wait per exchange epoch - per rank on stderr, rank 0's on the line
+    import re
+    for r in (0, 1):
+        mt = re.search(rf"\[bench\] rank {r}: exchange transport HIP-IPC device windows; peer {1 - r}: hop ([0-9.]+) us, wait per epoch mean ([0-9.]+) us max ([0-9.]+) us; (\d+) exchange epochs", p.stderr)
+        assert mt, p.stderr[-3000:]
+        hop, mean, mx, epochs = float(mt.group(1)), float(mt.group(2)), float(mt.group(3)), int(mt.group(4))
+        assert 0.2 < hop < 500 and mean > 0 and mx >= mean and epochs > line["config"]["work"]["sweeps"]
+    assert "flag hop through the windows" in p.stderr
+    ex = line["exchange"]
+    assert ex["transport"] == "HIP-IPC device windows" and set(ex["hop_us"]) == {"1"} and ex["epochs"] > 0
 
 
 @pytest.mark.gpu

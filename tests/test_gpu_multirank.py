@@ -256,3 +256,44 @@ def test_connect_without_finalize_is_refused(tmp_path):
         logs.append(o)
     assert all(p.returncode != 0 for p in procs), logs
     assert all("sf3d_dist_finalize" in o for o in logs), logs
+
+
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29641), (3, "projwin", 29642)])
+def test_topology_edit_after_connect_is_a_topography_error_on_every_rank(tmp_path, world, case, port):
+    """A setter that changes the graph (here setSurfaceProperties) after sf3d_dist_connect / finalize: the strip is frozen and its
+    build arrays have been released (trimHostStaging), so the next device call must answer SF3D_TOPOGRAPHY_ERROR on every rank
+    (round 4's advice: it read the released arrays and crashed, leaving the peers in their all-gather time-outs) and computeStep
+    returns NaN instead of stepping a model the peers no longer agree on."""
+    res = run_ranks(world, case + "_editafter", tmp_path, port)
+    for r in res:
+        assert int(r["set"]) == capi.OK
+        assert int(r["balance"]) == capi.TOPOGRAPHY_ERROR, int(r["balance"])
+        assert np.isnan(float(r["dt"]))
+
+
+@pytest.mark.parametrize("world,case,port", [(2, "c2f20", 29681), (3, "c2f60", 29683), (2, "projwin", 29685)])
+def test_rccl_sequencing_over_mock(tmp_path, world, case, port):
+    """SF3D_EXCHANGE=rccl - the exchange in the form north_star sketches: halos as grouped ncclSend / ncclRecv of packed buffers
+    (k_push_* packs, dist_unpack scatters), partial sums as an ncclAllGather, all queued by the host BETWEEN the kernels, separate
+    decision kernels - had never executed a call: RCCL refuses two ranks on one device and the test box has one GPU.  Here the nine
+    entry points are resolved from tests/librccl_mock.so (SF3D_RCCL_LIB; shared memory + stream-ordered copies, tests/rccl_mock.cpp)
+    so that the product's side of that path - loader, communicator set-up from rank 0's id in the blob, pack / unpack kernels, the host
+    sequencing of every exchange in a look-ahead batch, k_local_reduce + the rank-ordered combination, tear-down and re-connect after
+    a re-initialisation - runs with the ranks sharing the GPU.  Held bit for bit against the window transport: H, Se, every accepted
+    dt, every work counter (infiltration regime, runoff regime with Courant refusals and restore-best steps, a DEM outline cut
+    mid-row).  What the mock cannot tell: anything about xGMI, RCCL's own launch costs, or its progress guarantees."""
+    from criteria3d_amd import build
+    mock = build.build_rccl_mock()
+    win = run_ranks(world, case, tmp_path, port, env={"SF3D_PAIR_SWEEP": "0"})
+    rccl = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_EXCHANGE": "rccl", "SF3D_RCCL_LIB": str(mock), "SF3D_RCCL_SHARED_GPU": "1"})
+    owner = win[0]["owner"]
+    for r in range(world):
+        assert int(win[r]["transport"]) == 1 and int(rccl[r]["transport"]) == 3, (r, win[r]["transport"], rccl[r]["transport"])
+        mine = owner == r
+        for k in win[r].files:
+            if k.startswith(("H_h", "Se_h")):
+                assert np.array_equal(win[r][k][mine], rccl[r][k][mine]), (r, k)
+            elif k.startswith("dts_h") or k == "counters":
+                assert np.array_equal(win[r][k], rccl[r][k]), (r, k)
+            elif k.startswith(("storage_h", "total_water_h", "runoff_h", "drainage_h", "lateral_h")):
+                np.testing.assert_allclose(win[r][k], rccl[r][k], rtol=1e-12, atol=1e-300)
