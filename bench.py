@@ -214,6 +214,29 @@ def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20
         sim += dt
         nsteps += 1
     sf.lib.sf3d_clean()
+    # SURVEY 8d also asks for the reference's sources built "-O3 -march=x86-64-v3" (oracle/_ref/libsf3d_ref_tuned.so: FMA contraction
+    # changes the last bits, so it is a timing-only build): the SAME first nsteps steps, reported next to the project-flags figure
+    tuned = None
+    if kind == "reference":
+        try:
+            st = checkers.load_reference_tuned()
+            cm.build(st, model, threads=cores)
+            st.lib.sf3d_set_threads_number(cores)
+            st.set_sink_source_bulk(0, np.full(model.ns, cm.rain_rate(cm.FORCINGS[forcing](0), model.cell_area)))
+            tsim, twall, tn = 0.0, 0.0, 0
+            while tn < nsteps and tsim < 3600.0:
+                t0 = time.perf_counter()
+                dt = st.lib.sf3d_compute_step(3600.0 - tsim)
+                twall += time.perf_counter() - t0
+                if not (dt > 0.0):
+                    break
+                tsim += dt; tn += 1
+            st.lib.sf3d_clean()
+            if twall > 0 and tn > 0:
+                tuned = {"value": (tsim / 3600.0) / twall, "unit": "sim-h/s", "flags": "-O3 -march=x86-64-v3 -fopenmp (oracle/Makefile ref-tuned)",
+                         "sample": f"first {tn} computeStep calls ({tsim:.0f} simulated s), {twall:.1f} s wall", "cores": cores}
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cpu_baseline: tuned reference build not timed ({e})")
     # the GPU's wall time for the SAME first nsteps steps of the same run
     gpu_wall = None
     if gpu_steps and nsteps >= 1 and len(gpu_steps[1]) >= nsteps:
@@ -224,6 +247,7 @@ def cpu_baseline(cm, capi, model, forcing, workload_name, gpu_steps, budget_s=20
                      f"{wall:.1f} s wall"}
     if gpu_wall:
         out["gpu_same_sample_sim_h_per_s"] = (sim / 3600.0) / gpu_wall
+    out["tuned"] = tuned
     return out
 
 
@@ -479,7 +503,7 @@ def main():
     # cannot collect counters itself
     traffic, traffic_source, run_traffic = None, None, None
     try:
-        for tag in ("r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
+        for tag in ("r05_d", "r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
             f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
             if not f.exists():
                 continue
@@ -493,7 +517,9 @@ def main():
             break
         if traffic is None and world == 1 and args.workload == "C5" and not args.heat and dom:
             # the Ravone project: PMC passes of `bench.py --workload C5 --steps 1` (the paired sweep runs as k_sweep_pair_masked there)
-            f5 = ROOT / "profiles" / "r03_b_C5_pmc_traffic.json"
+            f5 = ROOT / "profiles" / "r05_d_C5_pmc_traffic.json"
+            if not f5.exists():
+                f5 = ROOT / "profiles" / "r03_b_C5_pmc_traffic.json"
             if f5.exists() and not (os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")):
                 p5 = json.load(open(f5))
                 k5 = "k_sweep_pair_masked" if dom == "k_sweep_pair" else dom

@@ -8,28 +8,30 @@ import pytest
 
 from criteria3d_amd import capi, catchment as cm
 from tests import scenarios as sc
+from tests.tolerances import WATER_RTOL
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-RTOL = 1e-6
+RTOL = WATER_RTOL          # 1e-9 (tests/tolerances.py); north_star: 1e-6
 
 
 env = sc.env
 
 
-FLOW_RTOL = {"up": 1e-5, "down": 1e-5, "lateral_max": 1e-3, "lateral_sum": 1e-3, "lateral_in": 1e-3, "lateral_out": 1e-3}
-# per element, for the sums above 1e-3 of the largest of their kind.  Measured (gpurun_out/r03f/flow_diag.txt, profiles/README.md):
-# up / down 2.6e-4 (C2 F20) ... 7e-9, laterals 9.7e-4 (lateral_sum, C2 F20: a sum of eight terms of both signs) ... 3e-8
-FLOW_ELEMENT_RTOL = {"up": 1e-3, "down": 1e-3, "lateral_max": 1e-3, "lateral_sum": 3e-3, "lateral_in": 1e-3, "lateral_out": 1e-3}
+# Rounds 1-4 needed bands of 1e-5 (vertical) ... 3e-3 (lateral sums, element-wise): a flow sum is a conductance times a DIFFERENCE of two
+# 100 m heads, and the surface ones go with millimetres of water to the power 5/3, so the last-ulp differences of the 0.50-ulp log / pow /
+# cbrt against glibc's came out amplified a thousandfold (measured then: 2.6e-4 ... 9.7e-4 on C2 F20).  With the C library's functions
+# reproduced bit for bit (round 5) the same sums agree to rounding of the additions: one band for all kinds.
+_F = max(WATER_RTOL, 1e-9)
+FLOW_RTOL = {k: _F for k in ("up", "down", "lateral_max", "lateral_sum", "lateral_in", "lateral_out")}
+# per element, for the sums above 1e-3 of the largest of their kind
+FLOW_ELEMENT_RTOL = {k: 1000 * _F for k in FLOW_RTOL}
 
 
 def flows_close(a, b, what):
-    """A link flow sum accumulates a_ij (H_i - H_j) dt.  Vertical links: a difference of two heads of ~100 m that are 0.1-1 m
-    apart, so the 1e-6 band of H (measured: 2e-10 ... 6e-8) is a 100-1000 times wider band of the difference - held to 1e-5 of the
-    largest sum of the same kind in the model (measured: 1.5e-6 on C2 F20 Up).  Lateral links are dominated by the surface
-    (runoff) links, whose conductance goes with Hs^(5/3), Hs = max(H) - max(z + pond) being MILLIMETRES of water computed from
-    those 100 m heads (water.cpp:413-487): 1e-8 of H is 1e-3 of Hs - held to 1e-3 of the largest sum of the kind (measured: 1.3e-4).
-    The boundary sums, which are balance terms, keep the 1e-6 of the north star."""
+    """A link flow sum accumulates a_ij (H_i - H_j) dt: held to FLOW_RTOL of the largest sum of the same kind in the model and, element
+    by element where the sum is not small, to FLOW_ELEMENT_RTOL of itself (a difference of two heads of ~100 m that are millimetres
+    to a metre apart: an error of 1e-12 of H is 1e-9 ... 1e-7 of such a difference)."""
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape
     for k, name in enumerate(cm.LINK_FLOW_FIELDS):
@@ -93,7 +95,7 @@ def test_urban_road_boundaries_vs_reference_vector(product):
     np.testing.assert_allclose(g["dts"], gold["dts"], rtol=1e-12)
     for h in (0, 1):
         assert np.max(np.abs(g[f"H_h{h}"] - gold[f"H_h{h}"]) / np.maximum(np.abs(gold[f"H_h{h}"]), 1e-9)) < RTOL
-        assert np.max(np.abs(g[f"Se_h{h}"] - gold[f"Se_h{h}"])) < 1e-6
+        assert np.max(np.abs(g[f"Se_h{h}"] - gold[f"Se_h{h}"])) < RTOL
     for k in ("total_water", "storage"):
         np.testing.assert_allclose(g[k], gold[k], rtol=RTOL)
     for k in ("runoff", "drainage", "lateral"):
@@ -104,16 +106,14 @@ def test_urban_road_boundaries_vs_reference_vector(product):
     product.lib.sf3d_clean()
 
 
-def _snap_close(g, o, tag, se_tol=1e-6, long_run=False):
+def _snap_close(g, o, tag, se_tol=RTOL, long_run=False):
     assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < RTOL, f"{tag}: H"
     assert np.max(np.abs(g["Se"] - o["Se"])) < se_tol, f"{tag}: Se"
     for k in ("total_water", "storage"):
         assert abs(g[k] - o[k]) <= RTOL * abs(o[k]), f"{tag}: {k} {g[k]!r} vs {o[k]!r}"
-    # cumulative boundary sums: each within 1e-6 of itself; in the 3-hour runoff-regime run 1e-5 of itself - the free-lateral-drainage
-    # sum goes with the Mualem conductivity of nearly saturated nodes, which amplifies the band of H about tenfold (measured after
-    # 10 000 steps: 1.05e-6 of itself, i.e. 4e-10 of the run's cumulative boundary outflow)
+    # cumulative boundary sums: each within RTOL of itself (ten times that in the 3-hour runoff-regime run: 10 000 steps of sums)
     for k in ("runoff", "drainage", "lateral"):
-        tol = (1e-5 if long_run else RTOL) * max(abs(o[k]), 1e-3)
+        tol = (10 * RTOL if long_run else RTOL) * max(abs(o[k]), 1e-3)
         assert abs(g[k] - o[k]) <= tol, f"{tag}: {k} {g[k]!r} vs {o[k]!r}"
 
 
@@ -206,9 +206,8 @@ def test_c2_f60_three_hours_stay_within_tolerance(product, oracle):
         o = cm.snapshot(oracle, m)
         assert len(gd) == len(od), (h, len(gd), len(od))
         np.testing.assert_allclose(gd, od, rtol=1e-12)
-        # Se follows from psi = H - z of a fraction of a metre: 1e-6 relative of H ~ 100 m is 1e-4 m of psi, i.e. up to ~3e-5 of Se on the
-        # steep part of the retention curve (measured after 2 h: H 3.7e-7, Se 1.4e-5) - Se is held to 1e-4 here, H to the 1e-6 itself
-        _snap_close(g, o, f"C2 F60 h{h}", se_tol=1e-4, long_run=True)
+        # (rounds 1-4 measured H 3.7e-7 and Se 1.4e-5 after two hours of this run: the last ulps of their own log / pow / cbrt)
+        _snap_close(g, o, f"C2 F60 h{h}", se_tol=100 * RTOL, long_run=True)
     gc, oc = product.counters(), oracle.counters()
     early = gc.pop("early_courant_rejections"); oc.pop("early_courant_rejections")      # (how the product got there, not what it did)
     assert gc == oc, (gc, oc)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from criteria3d_amd import capi, catchment as cm
+from tests.tolerances import WATER_RTOL
 
 pytestmark = pytest.mark.gpu
 
@@ -25,10 +26,10 @@ def test_c4_hour0_matches_oracle(product, oracle, c4):
     g = cm.snapshot(product, m)
     assert gs == len(od) == 22
     np.testing.assert_allclose(gd, od, rtol=1e-12)
-    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6
-    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6
+    assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < WATER_RTOL
+    assert np.max(np.abs(g["Se"] - o["Se"])) < WATER_RTOL
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
-        assert abs(g[k] - o[k]) <= 1e-6 * max(abs(o[k]), 1e-3), (k, g[k], o[k])
+        assert abs(g[k] - o[k]) <= WATER_RTOL * max(abs(o[k]), 1e-3), (k, g[k], o[k])
     gc = product.counters()
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections"):
         assert gc[k] == oc[k], (k, gc, oc)
@@ -270,6 +271,6 @@ def test_runoff_link_in_an_up_slot_switches_the_early_courant_check_off(product,
             g = cm.snapshot(product, m)
             gc = product.counters()
         np.testing.assert_allclose(gd, od, rtol=1e-12, err_msg=probe)
-        assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < 1e-6, probe
+        assert np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9)) < WATER_RTOL, probe
         assert gc["early_courant_rejections"] == 0 and gc["courant_rejections"] == oracle.counters()["courant_rejections"], (probe, gc)
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()

@@ -1,14 +1,15 @@
 """HIP product against the committed golden vectors of the UNMODIFIED reference
 (tests/golden/*.npz): every scenario, including the ragged graph (DEM holes, short columns,
 prescribed-potential boundary, evaporation / uptake sinks) and the alternative curve / mean types.
-Tolerance: north_star's 1e-6 relative on node H and the cumulative balances; accepted-dt sequences
-must be identical."""
+north_star asks for 1e-6 relative on node H and the cumulative balances; the water vectors are held to 1e-9 (tests/tolerances.py),
+the heat vectors to the 1e-6 (other sweep order than the reference's serial Gauss-Seidel); accepted-dt sequences must be identical."""
 from pathlib import Path
 
 import numpy as np
 import pytest
 
 from tests.scenarios import SCENARIOS, HEAT_SCENARIOS, env, run_scenario
+from tests.tolerances import WATER_RTOL as W
 
 pytestmark = pytest.mark.gpu
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -24,13 +25,13 @@ def test_product_matches_reference_vectors(product, name):
     for k in gold.files:
         a, b = np.asarray(trace[k], float), np.asarray(gold[k], float)
         if k.startswith("H_"):
-            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-9)) < 1e-6, k
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-9)) < W, k
         elif k.startswith("Se_"):
-            assert np.max(np.abs(a - b)) < 1e-6, k
+            assert np.max(np.abs(a - b)) < W, k
         elif k in ("total_water", "storage"):
-            assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b)), k
+            assert np.all(np.abs(a - b) <= W * np.abs(b)), k
         elif k in ("runoff", "drainage", "lateral"):
-            assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1e-3)), k
+            assert np.all(np.abs(a - b) <= W * np.maximum(np.abs(b), 1e-3)), k
         elif k == "mbr":
             assert np.all(np.abs(a - b) <= 1e-6), k            # a ratio of nearly cancelling terms: absolute
 

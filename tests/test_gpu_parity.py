@@ -1,15 +1,16 @@
 """Parity tests proper: the HIP product (through the C ABI) against the CPU oracle on the same
-inputs.  Tolerance is the one BASELINE.json's north_star states: node H and the cumulative mass
-balance within 1e-6 relative (fp64 path; transcendental functions of ROCm's ocml and glibc differ
-in the last ulp, the reductions are tree- instead of index-ordered)."""
+inputs.  BASELINE.json's north_star asks for node H and the cumulative mass balance within 1e-6 relative;
+the tests hold 1e-9 (tests/tolerances.py: the elementary functions are the reference C library's bit
+for bit since round 5, only the reductions are tree- instead of index-ordered)."""
 import numpy as np
 import pytest
 
 from criteria3d_amd import capi, catchment as cm
+from tests.tolerances import WATER_RTOL
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-6          # north_star: node H and cumulative mass balance within 1e-6 relative
+RTOL = WATER_RTOL    # north_star: node H and cumulative mass balance within 1e-6 relative; held: 1e-9 (tests/tolerances.py)
 
 
 def rel(a, b, floor=1e-9):
@@ -33,7 +34,7 @@ def run_pair(product, oracle, model, forcing, hours, use_period=False):
 
 def assert_snapshot_close(g, o, tag):
     assert rel(g["H"], o["H"]) < RTOL, f"{tag}: H"
-    assert np.max(np.abs(g["Se"] - o["Se"])) < 1e-6, f"{tag}: Se"
+    assert np.max(np.abs(g["Se"] - o["Se"])) < RTOL, f"{tag}: Se"
     for k in ("total_water", "storage"):
         assert abs(g[k] - o[k]) <= RTOL * abs(o[k]), f"{tag}: {k} {g[k]!r} vs {o[k]!r}"
     for k in ("runoff", "drainage", "lateral"):
@@ -57,7 +58,7 @@ def test_column_c1_compute_period_mbr(product, oracle):
         assert_snapshot_close(g, o, f"C1p h{h}")
         # MBR = (delta storage - cumulative sink) / max(1 litre, sink): a difference of nearly equal
         # numbers, so it is compared absolutely (it is judged against thresholds of 1e-3..1e-2)
-        assert abs(g["mbr"] - o["mbr"]) <= 1e-6, (g["mbr"], o["mbr"])
+        assert abs(g["mbr"] - o["mbr"]) <= 1e-6, (g["mbr"], o["mbr"])          # (storage differences of 1e-11 over a sink of litres)
 
 
 def test_catchment_c2_f20(product, oracle):
@@ -131,10 +132,10 @@ def test_getters_and_state_setters_roundtrip(product, oracle):
         for fn in ("get_node_total_potential", "get_node_matric_potential", "get_node_water_content",
                    "get_node_degree_of_saturation", "get_node_water_conductivity"):
             a, b = getattr(product, fn)(i), getattr(oracle, fn)(i)
-            assert abs(a - b) <= 1e-6 * max(abs(b), 1e-9), (fn, i, a, b)
+            assert abs(a - b) <= RTOL * max(abs(b), 1e-9), (fn, i, a, b)
     a = product.boundary_water_flow(0, m.n); b = oracle.boundary_water_flow(0, m.n)
-    assert rel(a, b, floor=1e-6) < 1e-5
-    assert abs(product.get_total_water_content() - oracle.get_total_water_content()) < 1e-6 * oracle.get_total_water_content()
+    assert rel(a, b, floor=1e-6) < 10 * RTOL
+    assert abs(product.get_total_water_content() - oracle.get_total_water_content()) < RTOL * oracle.get_total_water_content()
 
 
 def test_v1_alias_layer_runs_the_column(product):
