@@ -361,7 +361,8 @@ template <class T> void reset(std::vector<T>& v, size_t n) { v.assign(n, T()); }
 #define NEED_INIT_E   if (!M.initialized) return SF3D_MEMORY_ERROR
 #define NEED_NODE_E(i) if ((i) >= M.N) return SF3D_INDEX_ERROR
 #define NEED_INIT_D   if (!M.initialized) return errValue(SF3D_MEMORY_ERROR)
-#define NEED_NODE_D(i) if ((i) >= M.N) return errValue(SF3D_INDEX_ERROR)
+/* (a node of another rank's strip once the staging copy is trimmed: NODATA, like the bulk getters - sf3d_dist_owner says whose it is) */
+#define NEED_NODE_D(i) if ((i) >= M.N) return errValue(SF3D_INDEX_ERROR); if (skippedByTrim(i)) return (double)SF3D_NODATA
 
 }  // namespace
 
@@ -995,6 +996,11 @@ sf3d_error_t sf3d_synchronize(void)
 int sf3d_dist_blob_bytes(void) { return (int)sizeof(DistBlob); }
 sf3d_error_t sf3d_dist_prepare(int rank, int world)
 {
+    /* a connected, trimmed strip keeps only its own part of the graph: another (rank, world) needs the whole model again */
+    if (LM.trimmed && M.initialized && (rank != distRank || world != distWorld)) {
+        fprintf(stderr, "sf3d: dist_prepare(%d, %d) on a connected strip of (%d, %d): the staging copy holds this strip only - sf3d_clean / re-initialise first\n", rank, world, distRank, distWorld);
+        return SF3D_TOPOGRAPHY_ERROR;
+    }
     sf3d_error_t e = dev().dist_prepare(rank, world);
     if (e != SF3D_OK) fprintf(stderr, "sf3d: %s\n", dev().last_error());
     else {
@@ -1045,6 +1051,9 @@ sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t*
         for (uint32_t k = 0; k < count; ++k) out[k] = LM.gpart.owner[first + k];
         return SF3D_OK;
     }
+    /* the trimmed staging copy no longer holds the other ranks' links: a partition for another world cannot be derived from it
+     * (it would silently hand every foreign soil node to rank 0) */
+    if (LM.trimmed) return SF3D_MISSING_DATA_ERROR;
     Partition part;
     sf3d_error_t e = sf3d_compute_partition(M, 0, world, part);
     if (e != SF3D_OK) return e;

@@ -162,9 +162,11 @@ def test_bench_value_is_the_six_hour_episode_whatever_steps_is():
         out[steps] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     a, b = out[20], out[6]
     assert a["steps"] == 20 and a["warmup"] == 5 and a["headline_6h"]["value"] == a["value"]
-    # two separate runs of a launch-bound grid (0.26 ms per computeStep): 424 / 435 / 454 sim-h/s were measured for --steps 20 / 6 / 12 on
-    # one box - run-to-run noise; the committed C4 lines (--steps 6 and --steps 20 --warmup 5) are held to 3 % in the CPU test above
-    assert abs(a["value"] - b["value"]) < 0.08 * b["value"], (a["value"], b["value"])
+    # two separate runs of a launch-bound grid (0.26 ms per computeStep, the host's launch rate decides): 424 / 435 / 454 sim-h/s were
+    # measured for --steps 20 / 6 / 12 on one box, 444 against 394 on another while the suite's background worker kept the host cores
+    # busy - run-to-run noise; what this guards against is the round-3 defect (K hours over their time: 2.6 x between --steps 20 and 6);
+    # the committed C4 lines (--steps 6 and --steps 20 --warmup 5) are held to 3 % in the CPU test above
+    assert abs(a["value"] - b["value"]) < 0.25 * b["value"], (a["value"], b["value"])
     assert len(a["headline_6h"]["episodes_s"]) == 3 * 3 and a["timed_region"]["hours"] == 20
     assert a["config"]["work"]["accepted"] == 3 * 50 + 22 + 13          # three episodes (22 + 13 + 6 + 3 + 3 + 3) and hours 0, 1 of a fourth
     assert a["roofline"]["step"]["work"]["accepted"] == 50               # the step roofline describes ONE episode
