@@ -338,9 +338,14 @@ def main():
     if args.lineal:
         os.environ["SF3D_LINEAL_DEVICE_CG"] = "1"
 
+    # N > 1: every rank stages the whole model (the reference's API is global) unless SF3D_BENCH_STRIP_LOCAL_BUILD=1 asks for the
+    # strip-local build (include/sf3d.h: sf3d_dist_bounds - a rank stages its strip and the ring of columns around it only; same bits,
+    # tests/test_gpu_multirank.py).  The global build stays the default of the bench: it is what every earlier multi-rank run used.
+    strip_local = os.environ.get("SF3D_BENCH_STRIP_LOCAL_BUILD") == "1"
+
     def fresh():
         sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-        cm.build(sf, model, threads=1, dist=shard, heat=heat)
+        cm.build(sf, model, threads=1, dist=shard, heat=heat, sparse=strip_local and shard is not None)
         if args.lineal:
             sf.lib.sf3d_set_use_lineal(1)
         sf.check(sf.lib.sf3d_synchronize(), "synchronize")
@@ -590,7 +595,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload} {nx}x{ny}x{nz} " + ({"C5S": "synthetic Ravone-like DEM (irregular)", "C5": "Ravone project (DATA/PROJECT/Ravone: DEM, soil map, soil_ER_2021.db, land use; 13 soil layers to 0.95 m)", "C5DEM": "Ravone DEM with synthetic soils (round-2 stand-in)"}.get(args.workload, "tilted-plane catchment (SURVEY.md 8d)") + (" + coupled heat transport" if args.heat else "")) + (", linear systems by device conjugate gradients (setUseLineal)" if args.lineal else "") + f", forcing {args.forcing}, "
                                + (f"the 6-hour episode from the initial state; {args.steps} timed hours = {args.steps // EPISODE_HOURS} complete episode(s)" + (f" + {args.steps % EPISODE_HOURS} more hour(s)" if args.steps % EPISODE_HOURS else "") + f" per repetition, {reps} repetitions, `value` = 6 h / median episode" if elapsed_6h else f"{args.steps} simulated hours from the initial state (median of {reps} repetitions)"),
-                   "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else (f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI" if replicas is None else f"{world} INDEPENDENT REPLICAS of the workload (the strip exchange could not be set up on this node: {replicas})"),
+                   "nodes": model.n, "forcing": args.forcing, "partition": "single GPU" if world == 1 else (f"{world} row strips of surface-cell columns, one-cell halos over HIP-IPC/xGMI" + (", strip-local build" if strip_local else "") if replicas is None else f"{world} INDEPENDENT REPLICAS of the workload (the strip exchange could not be set up on this node: {replicas})"),
                    "work": work},
         "repeats_s": rep_elapsed,
         "headline_6h": ({"value": EPISODE_HOURS / elapsed_6h, "unit": "sim-h/s", "hours": "one complete episode, hours 0-5 (SURVEY.md 8d headline workload) = `value`",

@@ -157,6 +157,7 @@ SIGNATURES = {
     "sf3d_dist_stats": (u8, [pd, i32]),
     "sf3d_get_regular_grid": (u8, [p32, p32, p32, C.POINTER(C.c_int8), C.POINTER(C.c_int8)]),
     "sf3d_dist_owner": (u8, [i32, u32, u32, C.POINTER(C.c_int32)]),
+    "sf3d_dist_bounds": (u8, [u32, i32, p32]),
     "sf3d_dist_halo": (u8, [i32, i32, i32, i32, u32, p32, p32]),
 }
 
@@ -334,6 +335,13 @@ class SF3D:
         self.check(self.lib.sf3d_dist_stats(out.ctypes.data_as(pd), out.size), "dist_stats")
         return {"epochs": int(out[0]), "peers": {p: {"hop_us": float(out[1 + 3 * p]), "mean_wait_us": float(out[2 + 3 * p]), "max_wait_us": float(out[3 + 3 * p])}
                                                  for p in range(world)}}
+
+    def dist_bounds(self, ns, world):
+        """surface-index bounds of the row strips of `world` ranks (world + 1 entries): rank r owns the columns of the surface nodes
+        [bounds[r], bounds[r + 1]) - needs no model"""
+        out = np.zeros(world + 1, dtype=np.uint32)
+        self.check(self.lib.sf3d_dist_bounds(ns, world, _ptr(out, u32)), "dist_bounds")
+        return out
 
     def owner_map(self, world, n):
         out = np.empty(n, dtype=np.int32)

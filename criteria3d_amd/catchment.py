@@ -254,21 +254,62 @@ def heat_forcing(h: int) -> dict:
                 wind_speed=2.0 + 1.0 * np.cos(ph), net_irradiance=max(0.0, 350.0 * np.sin(ph - np.pi / 2)) - 40.0)
 
 
-def apply_heat_forcing(sf: capi.SF3D, m: Model, h: int):
-    nodes = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE).astype(np.uint32)
+def apply_heat_forcing(sf: capi.SF3D, m: Model, h: int, staged=None):
+    if staged is None:
+        staged = m.meta.get("staged")
+    sel = m.btype == capi.BND_HEAT_SURFACE
+    nodes = np.flatnonzero(sel if staged is None else (sel & staged)).astype(np.uint32)
     for k, v in heat_forcing(h).items():
         sf.set_boundary_heat_bulk(k, nodes, v)
 
 
-def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool = True, heat: Heat | None = None):
+def column_of(m: Model) -> np.ndarray:
+    """surface ancestor of every node through the Up links (the column a node belongs to); a soil node without an Up link counts as
+    column 0 - the library's rule for orphans (sf3d_compute_partition)"""
+    up = m.link_dir == capi.LINK_UP
+    parent = np.arange(m.n)
+    parent[m.link_node[up]] = m.link_to[up]
+    root = parent.copy()
+    for _ in range(64):
+        nxt = parent[root]
+        if np.array_equal(nxt, root):
+            break
+        root = nxt
+    return np.where(root < m.ns, root, 0)
+
+
+def strip_nodes(sf: capi.SF3D, m: Model, rank: int, world: int) -> np.ndarray:
+    """STRIP-LOCAL BUILD (include/sf3d.h: sf3d_dist_bounds): boolean mask of the nodes rank `rank` of `world` has to stage - the columns
+    whose surface node lies in its index range and the one-cell ring of columns around them, every column whole"""
+    bounds = sf.dist_bounds(m.ns, world)
+    col = column_of(m)
+    owned = (col >= bounds[rank]) & (col < bounds[rank + 1])
+    ring = np.unique(col[m.link_to[owned[m.link_node]]])
+    need = np.zeros(m.ns, dtype=bool)
+    need[np.unique(col[owned])] = True
+    need[ring] = True
+    return need[col]
+
+
+def _runs(mask: np.ndarray, lo: int, hi: int):
+    """maximal runs [a, b) of True inside mask[lo:hi]"""
+    w = np.flatnonzero(np.diff(np.concatenate(([False], mask[lo:hi], [False])).astype(np.int8)))
+    return [(lo + int(a), lo + int(b)) for a, b in zip(w[0::2], w[1::2])]
+
+
+def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool = True, heat: Heat | None = None, sparse: bool = False):
     """Push a Model through the ABI in the caller's order.
 
     dist = (rank, world, allgather) shards the model over `world` ranks (HIP product only):
-    every rank pushes the same global model; `allgather(bytes) -> list[bytes]` is the launcher's
+    every rank pushes the same global model - or, with sparse=True, only the nodes its strip touches (strip_nodes: the strip-local
+    build of include/sf3d.h); `allgather(bytes) -> list[bytes]` is the launcher's
     control-plane exchange (torch.distributed all_gather_object in bench.py and the tests)."""
+    keep = None
     if dist is not None:
         rank, world, allgather = dist
         sf.check(sf.lib.sf3d_dist_prepare(rank, world), "dist_prepare")
+        if sparse and world > 1:
+            keep = strip_nodes(sf, m, rank, world)
     if heat is None:
         sf.check(sf.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
     else:
@@ -283,13 +324,28 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
         sf.check(sf.lib.sf3d_set_soil_properties(k, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"],
                                                  s["theta_r"], s["theta_s"], s["ksat"], s["L"],
                                                  s["organic_matter"], s["clay"]), "set_soil_properties")
-    sf.set_nodes_bulk(0, m.x, m.y, m.z, m.size, m.is_surface, m.btype, m.bslope, m.barea)
-    sf.set_links_bulk(m.link_node, m.link_to, m.link_dir, m.link_area)
-    if m.ns > 0:
-        sf.set_surface_bulk(0, m.surface_index if m.surface_index is not None else np.zeros(m.ns, np.uint16))
-        sf.set_pond_bulk(0, m.pond_node if m.pond_node is not None else np.full(m.ns, m.pond))
-    if m.n > m.ns:
-        sf.set_soil_bulk(m.ns, m.soil_index, m.horizon_index if m.horizon_index is not None else np.zeros(m.n - m.ns, np.uint16))
+    if keep is None:
+        sf.set_nodes_bulk(0, m.x, m.y, m.z, m.size, m.is_surface, m.btype, m.bslope, m.barea)
+        sf.set_links_bulk(m.link_node, m.link_to, m.link_dir, m.link_area)
+        if m.ns > 0:
+            sf.set_surface_bulk(0, m.surface_index if m.surface_index is not None else np.zeros(m.ns, np.uint16))
+            sf.set_pond_bulk(0, m.pond_node if m.pond_node is not None else np.full(m.ns, m.pond))
+        if m.n > m.ns:
+            sf.set_soil_bulk(m.ns, m.soil_index, m.horizon_index if m.horizon_index is not None else np.zeros(m.n - m.ns, np.uint16))
+    else:
+        # the same calls for the runs of nodes this rank stages (global indices; in layer-major numbering one run per layer)
+        for a, b in _runs(keep, 0, m.n):
+            sf.set_nodes_bulk(a, m.x[a:b], m.y[a:b], m.z[a:b], m.size[a:b], m.is_surface[a:b], m.btype[a:b], m.bslope[a:b], m.barea[a:b])
+        lk = keep[m.link_node]
+        sf.set_links_bulk(m.link_node[lk], m.link_to[lk], m.link_dir[lk], m.link_area[lk])
+        surf = m.surface_index if m.surface_index is not None else np.zeros(m.ns, np.uint16)
+        pond = m.pond_node if m.pond_node is not None else np.full(m.ns, m.pond)
+        for a, b in _runs(keep, 0, m.ns):
+            sf.set_surface_bulk(a, surf[a:b])
+            sf.set_pond_bulk(a, pond[a:b])
+        hor = m.horizon_index if m.horizon_index is not None else np.zeros(m.n - m.ns, np.uint16)
+        for a, b in _runs(keep, m.ns, m.n):
+            sf.set_soil_bulk(a, m.soil_index[a - m.ns:b - m.ns], hor[a - m.ns:b - m.ns])
     sf.check(sf.lib.sf3d_set_hydraulic_properties(capi.WRC_MODIFIED_VG, capi.MEAN_LOGARITHMIC, m.lv_ratio),
              "set_hydraulic_properties")
     sf.check(sf.lib.sf3d_set_numerical_parameters(*m.numerics), "set_numerical_parameters")
@@ -306,18 +362,26 @@ def build(sf: capi.SF3D, m: Model, threads: int = 1, dist=None, finalize: bool =
                 break
             root = nxt
         depth = m.z[root] - m.z
-        sf.set_temperature_bulk(0, heat.t0_surface + heat.t0_gradient * depth)
+        t0 = heat.t0_surface + heat.t0_gradient * depth
+        for a, b in ([(0, m.n)] if keep is None else _runs(keep, 0, m.n)):
+            sf.set_temperature_bulk(a, t0[a:b])
     psi = np.full(m.n, m.psi0_soil)
     psi[:m.ns] = m.psi0_surface
-    sf.set_matric_potential_bulk(0, psi)
+    for a, b in ([(0, m.n)] if keep is None else _runs(keep, 0, m.n)):
+        sf.set_matric_potential_bulk(a, psi[a:b])
     if heat is not None:
-        hs = np.flatnonzero(m.btype == capi.BND_HEAT_SURFACE).astype(np.uint32)
+        staged = np.ones(m.n, dtype=bool) if keep is None else keep
+        hs = np.flatnonzero((m.btype == capi.BND_HEAT_SURFACE) & staged).astype(np.uint32)
         sf.set_boundary_heat_bulk("height_wind", hs, heat.height_wind)
         sf.set_boundary_heat_bulk("height_temperature", hs, heat.height_temperature)
         sf.set_boundary_heat_bulk("roughness", hs, heat.roughness_height)
-        apply_heat_forcing(sf, m, 0)
-        for i in np.flatnonzero(m.btype == capi.BND_FREE_DRAINAGE):
+        apply_heat_forcing(sf, m, 0, staged)
+        for i in np.flatnonzero((m.btype == capi.BND_FREE_DRAINAGE) & staged):
             sf.check(sf.lib.sf3d_set_node_boundary_fixed_temperature(int(i), heat.fixed_temperature, heat.fixed_depth), "fixed_temperature")
+    if keep is not None:
+        m.meta["staged"] = keep          # (apply_heat_forcing of this rank touches only what it staged)
+    else:
+        m.meta.pop("staged", None)
     if not finalize:          # host-side staging only (partition queries on a machine without a GPU)
         return
     if dist is not None:

@@ -162,6 +162,9 @@ sf3d_error_t buildLocal()
 {
     Partition& gp = LM.gpart;
     sf3d_error_t e = sf3d_compute_partition(M, distRank, distWorld, gp);
+    if (e == SF3D_MISSING_DATA_ERROR && gp.missingFrom != UINT32_MAX)
+        fprintf(stderr, "sf3d: rank %d: node %u of this rank's strip is linked to node %u, which was never given a soil / surface class - a strip-local "
+                        "build must stage the whole one-cell ring of columns around the strip\n", distRank, gp.missingFrom, gp.missingTo);
     if (e != SF3D_OK) return e;
     LM.trimmed = false;
     std::vector<uint8_t> in(M.N, 0);
@@ -176,7 +179,6 @@ sf3d_error_t buildLocal()
     L.N = (uint32_t)LM.l2g.size();
     L.ns = 0; for (uint32_t g : LM.l2g) if (g < M.ns) ++L.ns;
     L.globalN = M.N;
-    L.heatTwoColour = (M.heat && heat_two_colour_valid(M)) ? 1 : 0;      /* decided on the global graph: the same answer on every rank */
     gatherTo(L.x, M.x); gatherTo(L.y, M.y); gatherTo(L.z, M.z); gatherTo(L.size, M.size); gatherTo(L.surf, M.surf);
     gatherTo(L.hasClass, M.hasClass); gatherTo(L.cls, M.cls); gatherTo(L.btype, M.btype); gatherTo(L.bslope, M.bslope); gatherTo(L.bsize, M.bsize);
     gatherTo(L.bflowRate, M.bflowRate); gatherTo(L.bflowSum, M.bflowSum); gatherTo(L.prescribed, M.prescribed); gatherTo(L.nLat, M.nLat);
@@ -299,7 +301,7 @@ HostModel& deviceModel()
         if (buildLocal() != SF3D_OK) {
             /* (the partition fails only for a bad rank / world, which sf3d_dist_prepare has refused already) - never hand a half-built
              * model to the solver: an empty one fails its upload loudly */
-            fprintf(stderr, "sf3d: strip-local model: partition failed\n");
+            fprintf(stderr, "sf3d: strip-local model: partition failed (bad rank / world, or a strip-local build without its halo columns)\n");
             LM.L = HostModel(); LM.built = false;
         }
         return LM.L;
@@ -401,6 +403,9 @@ sf3d_error_t sf3d_initialize(uint32_t n, uint32_t ns, uint8_t nLat, int w, int h
                             &M.bFixT, &M.bFixDepth, &M.bAero, &M.bSoilCond, &M.bSens, &M.bLat, &M.bRad, &M.bAdv}) reset(*v, n);
         }
     } catch (const std::bad_alloc&) { return SF3D_MEMORY_ERROR; }
+    /* a rank of a multi-GPU run may stage only its strip and the ring of columns around it (sf3d_dist_bounds): the freshly zeroed
+     * pages go back to the system now and come back - still zero - where a setter writes, so what a rank never stages costs nothing */
+    if (LM.on && distWorld > 1) forEachArray(M, [&](auto& v) { releasePages(v, 0, v.size()); });
     M.initialized = true;
     if (P.dtCurr == SF3D_NODATA) P.dtCurr = P.dtMax;               /* CPUSolver::initialize, cpusolver.cpp:30-31 */
     M.solverReady = true;
@@ -1047,19 +1052,21 @@ sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t*
 {
     if (!M.initialized) return SF3D_MEMORY_ERROR;
     if ((uint64_t)first + count > M.N) return SF3D_INDEX_ERROR;
+    auto rankOf = [](uint8_t o) -> int32_t { return o == SF3D_OWNER_NONE ? -1 : (int32_t)o; };      /* -1: a node this rank never staged (strip-local build) */
     if (LM.trimmed && world == distWorld && LM.gpart.owner.size() == M.N) {      /* (M no longer holds the other ranks' links) */
-        for (uint32_t k = 0; k < count; ++k) out[k] = LM.gpart.owner[first + k];
+        for (uint32_t k = 0; k < count; ++k) out[k] = rankOf(LM.gpart.owner[first + k]);
         return SF3D_OK;
     }
     /* the trimmed staging copy no longer holds the other ranks' links: a partition for another world cannot be derived from it
      * (it would silently hand every foreign soil node to rank 0) */
     if (LM.trimmed) return SF3D_MISSING_DATA_ERROR;
     Partition part;
-    sf3d_error_t e = sf3d_compute_partition(M, 0, world, part);
+    sf3d_error_t e = sf3d_compute_partition(M, LM.on ? distRank : 0, world, part);
     if (e != SF3D_OK) return e;
-    for (uint32_t k = 0; k < count; ++k) out[k] = part.owner[first + k];
+    for (uint32_t k = 0; k < count; ++k) out[k] = rankOf(part.owner[first + k]);
     return SF3D_OK;
 }
+sf3d_error_t sf3d_dist_bounds(uint32_t nrSurfaceNodes, int world, uint32_t* bounds) { return sf3d_partition_bounds(nrSurfaceNodes, world, bounds); }
 /* Is the node graph a regular NX x NY x NZ grid in the layer-major numbering i = (l NY + r) NX + c with the ten-link stencil
  * (up, down, up to eight laterals to the 8-neighbourhood of the same layer)?  Host logic over the staged links; groundwork for
  * the two-iterations-per-pass sweep, which needs exactly this structure.  dr/dc: row / column step of lateral

@@ -71,8 +71,6 @@ struct HostModel {
      * GLOBAL node count */
     const struct Partition* presetPartition = nullptr;
     uint32_t globalN = 0;                       /* 0: this IS the global model */
-    int heatTwoColour = -1;                     /* strip-local model: whether the GLOBAL graph admits the two-colour heat sweep (heat_two_colour_valid below; every rank
-                                                 * must take the same decision); -1: decide on this model */
     /* what the host lacks (device is newer) */
     bool hostStaleState = false; /* H, Se, K                                                      */
     bool hostStaleFlows = false; /* bflowRate, bflowSum, lflowSum                                 */
@@ -103,13 +101,16 @@ inline bool heat_two_colour_valid(const HostModel& m)
  * walking Up links); surface nodes [0, ns) are cut into `world` contiguous index ranges at
  * multiples of 64.  send[p] / recv[p] are the sorted unique node lists exchanged with rank p
  * (what p's rows read from my strip / what my rows read from p's strip). */
+#define SF3D_OWNER_NONE 255u       /* Partition::owner of a node that was never staged on this rank (strip-local build) */
 struct Partition {
     int world = 1, rank = 0;
-    std::vector<uint8_t> owner;                       /* [N] */
+    std::vector<uint8_t> owner;                       /* [N]; SF3D_OWNER_NONE: absent */
+    uint32_t missingFrom = UINT32_MAX, missingTo = UINT32_MAX;   /* first link from one of this rank's nodes to an absent node (SF3D_MISSING_DATA_ERROR) */
     std::vector<uint32_t> bounds;                     /* [world + 1] surface-index strip bounds */
     std::vector<std::vector<uint32_t>> send, recv;    /* [world] */
 };
 sf3d_error_t sf3d_compute_partition(const HostModel& m, int rank, int world, Partition& out);
+sf3d_error_t sf3d_partition_bounds(uint32_t ns, int world, uint32_t* bounds);      /* [world + 1] surface-index strip bounds: a function of ns and world alone */
 
 /* what each rank publishes to the others before the first step (sf3d_dist_export/connect) */
 struct DistBlob {
@@ -118,7 +119,8 @@ struct DistBlob {
     uint32_t recvCount[SF3D_MAX_RANKS];
     uint32_t world, rank;
     uint64_t nodes;
-    uint32_t generation, pad;       /* export count of the rank; rank 0's value stamps the self-check token of a connect */
+    uint32_t generation;            /* export count of the rank; rank 0's value stamps the self-check token of a connect */
+    uint32_t heatJacobiOnly;        /* 1: this rank's part of the graph does not admit the two-colour heat sweep (heat_two_colour_valid): every rank then sweeps by Jacobi */
     unsigned char ncclId[128];     /* rank 0: ncclUniqueId of the run's RCCL communicator (all zero when RCCL is not available) */
     char pciBusId[32];             /* which physical GPU the rank runs on (start-up self-check: distinct, peer-reachable devices) */
     char shmName[48];              /* POSIX shared-memory object holding a second copy of the rank's window in HOST memory: the fall-back

@@ -427,13 +427,23 @@ int          sf3d_dist_transport(void);
  * for rank p's mailbox per epoch [us] (hop + how far p runs behind), out[3 + 3 p] = the longest single wait [us].
  * capacity >= 1 + 3 * world doubles, else SF3D_MEMORY_ERROR; SF3D_MISSING_DATA_ERROR without a connected multi-rank model. */
 sf3d_error_t sf3d_dist_stats(double* out, int capacity);
-/* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device) */
+/* owning rank of nodes first..first+count-1 for a world of `world` ranks (host logic, no device); -1: a node this rank never staged */
 /* Host logic, no device needed: SF3D_OK and the shape if the staged node graph is a regular NX x NY x NZ grid in layer-major
  * numbering i = (l NY + r) NX + c with the ten-link stencil (slot 0 up, 1 down, laterals to the 8-neighbourhood of the layer;
  * dr[k], dc[k]: row / column step of lateral slot k at a node that has all eight - edge nodes fill their slots in their own order),
  * SF3D_MISSING_DATA_ERROR otherwise (irregular DEM outlines, other numberings).  dr, dc: 8 entries each. */
 sf3d_error_t sf3d_get_regular_grid(uint32_t* nx, uint32_t* ny, uint32_t* nz, int8_t* dr, int8_t* dc);
 sf3d_error_t sf3d_dist_owner(int world, uint32_t first, uint32_t count, int32_t* owner_out);
+/* STRIP-LOCAL BUILD.  The setters are global (the reference's API is), but a rank of a multi-GPU run need not stage the whole model:
+ * rank r owns the surface-cell columns whose surface node index lies in [bounds[r], bounds[r + 1]) - a function of nrSurfaceNodes and
+ * world alone, returned here without a model (bounds: world + 1 entries; cuts at multiples of 64) - and computes only their rows.  It
+ * is enough to call setNode / setNodeLink / setNodeSoil / setNodeSurface / the state setters for the nodes of those columns AND of the
+ * one-cell ring of columns around them (every column whole, with all its links), after sf3d_dist_prepare and initializeSF3D with the
+ * GLOBAL node counts and with GLOBAL indices.  A node that never receives its soil / surface class is absent: it costs no memory
+ * (sf3d_host_bytes), joins no exchange list and reads as NODATA; a link from one of the rank's own nodes to an absent node is
+ * SF3D_MISSING_DATA_ERROR at the first device call (a forgotten halo column), and the halo counts of the two sides of every exchange
+ * are compared at sf3d_dist_connect.  Staging everything (the global build) stays valid and gives the same bits. */
+sf3d_error_t sf3d_dist_bounds(uint32_t nrSurfaceNodes, int world, uint32_t* bounds);
 /* halo lists of `rank` in a world of `world`: direction 0 = nodes sent to `peer`, 1 = nodes received
  * from `peer` (sorted global indices; pass out = NULL to query the count) */
 sf3d_error_t sf3d_dist_halo(int rank, int world, int peer, int direction, uint32_t capacity,

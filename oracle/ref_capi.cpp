@@ -195,6 +195,7 @@ int sf3d_dist_status(void) { return 0; }
 sf3d_error_t sf3d_dist_finalize(int) { return SF3D_MISSING_DATA_ERROR; }
 int sf3d_dist_transport(void) { return 0; }
 sf3d_error_t sf3d_dist_stats(double*, int) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_dist_bounds(uint32_t, int, uint32_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_get_regular_grid(uint32_t*, uint32_t*, uint32_t*, int8_t*, int8_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_dist_owner(int, uint32_t, uint32_t, int32_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_dist_halo(int, int, int, int, uint32_t, uint32_t*, uint32_t*) { return SF3D_MISSING_DATA_ERROR; }

@@ -49,13 +49,16 @@ elif case == "heat":
 else:
     raise SystemExit("unknown case")
 heat = cm.Heat(water=True, latent=True, save_mode=0) if case == "heat" else None
+sparse = os.environ.get("SF3D_TEST_SPARSE_BUILD") == "1"      # strip-local build: this rank stages its strip and the ring of columns around it only
 # a throw-away model first: re-initialisation must drop the windows, re-export and re-connect
 sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
 if case not in ("ravone", "c4f20h0"):
-    cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
+    cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat, sparse=sparse)
     cm.run_hour(sf, m, 5.0, max_steps=2)
     sf.check(sf.lib.sf3d_reset_solver_state(), "reset")
-cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat)
+t_build = time.time()
+cm.build(sf, m, threads=1, dist=(rank, world, allgather), heat=heat, sparse=sparse)
+t_build = time.time() - t_build
 if edit_after:
     # a graph-dirtying setter AFTER connect / finalize (the strip's build arrays are trimmed by then): every rank must get the
     # documented TopographyError from the next device call - no crash, no peer left in a time-out - and a NaN from computeStep
@@ -83,6 +86,9 @@ for h, item in enumerate(plan):
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
         res[f"{k}_h{h}"] = np.array(s[k])
 res["seconds"] = np.array(time.time() - t0)
+res["build_seconds"] = np.array(t_build)
+import resource
+res["maxrss_mb"] = np.array(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024)      # peak resident set of the rank process (model arrays of the caller included)
 res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 res["host_bytes_end"] = np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)
 c = sf.counters()

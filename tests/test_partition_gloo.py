@@ -40,3 +40,66 @@ def test_strips_are_row_blocks_cut_at_chunk_boundaries(product):
     assert np.array_equal(product.halo_list(0, 4, 1, 0), up)             # what 0 sends to 1 is what 1 receives from 0
     assert product.lib.sf3d_dist_prepare(5, 4) == capi.PARAMETER_ERROR
     product.lib.sf3d_clean()
+
+
+def _models():
+    from tests.scenarios import ravone_project_model
+    return {"grid": lambda: cm.catchment_model(128, 48, 5), "het": lambda: cm.catchment_model(64, 40, 6, heterogeneous=True),
+            "ragged": lambda: cm.ragged_model(9, 24, 4), "holes": lambda: cm.random_model(23, nx=70, ny=45, nz=5),
+            "project window": lambda: ravone_project_model((980, 1060, 330, 420))}
+
+
+@pytest.mark.parametrize("name,world", [("grid", 2), ("grid", 8), ("het", 3), ("ragged", 2), ("holes", 3), ("project window", 2), ("project window", 4)])
+def test_strip_local_build_gives_the_partition_of_the_global_build(product, name, world):
+    """STRIP-LOCAL BUILD (include/sf3d.h: sf3d_dist_bounds).  A rank that stages only the columns of its strip and the one-cell ring
+    of columns around them - found from sf3d_dist_bounds and the model's links alone (catchment.strip_nodes), global indices - must
+    arrive at the partition the global build gives it: the same owner for every node it staged (-1 for the others), the same halo
+    lists towards every peer in both directions.  Host logic only (no device); what it buys is measured too: the resident staging
+    memory of a rank (sf3d_host_bytes) shrinks to its strip."""
+    m = _models()[name]()
+    for rank in range(world):
+        cm.build(product, m, dist=(rank, world, None), finalize=False)
+        g_owner = product.owner_map(world, m.n)
+        g_lists = {(p, d): product.halo_list(rank, world, p, d) for p in range(world) for d in (0, 1)}
+        g_bytes = int(product.lib.sf3d_host_bytes())
+        product.lib.sf3d_clean()
+        cm.build(product, m, dist=(rank, world, None), finalize=False, sparse=True)
+        keep = m.meta["staged"]
+        s_owner = product.owner_map(world, m.n)
+        assert np.array_equal(s_owner[keep], g_owner[keep]) and (s_owner[~keep] == -1).all(), (name, world, rank)
+        assert (g_owner[keep] == rank).sum() == (g_owner == rank).sum()          # every node of the strip was staged
+        for (p, d), want in g_lists.items():
+            assert np.array_equal(product.halo_list(rank, world, p, d), want), (name, world, rank, p, d)
+        s_bytes = int(product.lib.sf3d_host_bytes())
+        if world >= 4 and name == "grid":
+            assert s_bytes < 0.6 * g_bytes, (s_bytes, g_bytes)
+        product.lib.sf3d_clean()
+    product.check(product.lib.sf3d_dist_prepare(0, 1), "dist_prepare")
+
+
+def test_strip_local_build_without_its_halo_columns_is_refused(product):
+    """a rank that stages its own columns but forgets the ring around them: one of its nodes links to a node that never got a class -
+    MissingDataError from the partition (with the two node numbers on stderr) instead of a wrong halo later"""
+    m = cm.catchment_model(64, 32, 4)
+    bounds = product.dist_bounds(m.ns, 2)
+    assert list(bounds) == [0, 1024, 2048]                                          # 32 rows of 64 cells cut in two at a multiple of 64
+    col = cm.column_of(m)
+    product.check(product.lib.sf3d_dist_prepare(1, 2), "dist_prepare")
+    product.check(product.lib.sf3d_initialize(m.n, m.ns, 8, 1, 0, 0, 0), "initialize")
+    product.check(product.lib.sf3d_set_surface_properties(0, 0.05), "surface")
+    s = m.soils[0]
+    product.check(product.lib.sf3d_set_soil_properties(0, 0, s["alpha"], s["n"], 1.0 - 1.0 / s["n"], s["he"], s["theta_r"], s["theta_s"], s["ksat"], s["L"],
+                                                        s["organic_matter"], s["clay"]), "soil")
+    own = col >= bounds[1]
+    for a, b in cm._runs(own, 0, m.n):
+        product.set_nodes_bulk(a, m.x[a:b], m.y[a:b], m.z[a:b], m.size[a:b], m.is_surface[a:b], m.btype[a:b], m.bslope[a:b], m.barea[a:b])
+    lk = own[m.link_node]
+    product.set_links_bulk(m.link_node[lk], m.link_to[lk], m.link_dir[lk], m.link_area[lk])
+    for a, b in cm._runs(own, 0, m.ns):
+        product.set_surface_bulk(a, np.zeros(b - a, np.uint16))
+    for a, b in cm._runs(own, m.ns, m.n):
+        product.set_soil_bulk(a, m.soil_index[a - m.ns:b - m.ns], np.zeros(b - a, np.uint16))
+    cnt = capi.u32(0)
+    assert product.lib.sf3d_dist_halo(1, 2, 0, 1, 0, None, capi.C.byref(cnt)) == capi.MISSING_DATA_ERROR
+    product.lib.sf3d_clean()
+    product.check(product.lib.sf3d_dist_prepare(0, 1), "dist_prepare")
