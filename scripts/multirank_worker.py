@@ -87,8 +87,9 @@ for h, item in enumerate(plan):
         res[f"{k}_h{h}"] = np.array(s[k])
 res["seconds"] = np.array(time.time() - t0)
 res["build_seconds"] = np.array(t_build)
-import resource
-res["maxrss_mb"] = np.array(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss // 1024)      # peak resident set of the rank process (model arrays of the caller included)
+# peak resident set of THIS process image (model arrays of the caller included).  VmHWM belongs to the address space - which exec
+# replaces - while getrusage's ru_maxrss is inherited from the parent at fork (a 20 GB pytest session reads as 20 GB in every child)
+res["maxrss_mb"] = np.array(next(int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmHWM:")) // 1024)
 res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 res["host_bytes_end"] = np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)
 c = sf.counters()
