@@ -265,3 +265,19 @@ def test_random_irregular_models_with_every_fast_path_forced(product, oracle, se
     for k in ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores"):
         assert gc[k] == oc[k], (k, gc, oc)
     oracle.lib.sf3d_clean(); product.lib.sf3d_clean()
+
+
+def test_sf3d_devices_picks_the_gpu_of_an_unmodified_caller():
+    """SF3D_DEVICES: which GPU a caller that never calls sf3d_set_device runs on - entry LOCAL_RANK of the list; a device
+    that does not exist is a SolverError at the first device call, not a silent device 0"""
+    import os
+    import subprocess
+    import sys
+    code = ("from criteria3d_amd import capi, catchment as cm\n"
+            "sf = capi.load_product(); m = cm.column_model()\n"
+            "sf.check(sf.lib.sf3d_reset_solver_state(), 'reset')\n"
+            "try:\n    cm.build(sf, m)\n    print('built', sf.lib.sf3d_compute_step(60.0) > 0)\nexcept capi.SF3DError as e:\n    print('refused', e)\n")
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SF3D_DEVICES="0,0", LOCAL_RANK="1"), timeout=300)
+    assert "built True" in ok.stdout, ok.stdout + ok.stderr
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SF3D_DEVICES="0,97", LOCAL_RANK="1"), timeout=300)
+    assert "refused" in bad.stdout and "SF3D_DEVICES names device 97" in (bad.stdout + bad.stderr), bad.stdout + bad.stderr
