@@ -54,7 +54,8 @@ def segment(sf, m, H0, dt0, steps, threads=16, heat=None, T0=None, hour=1, more=
 
 def compare(g, o):
     """metrics of one compared segment: product (g) against a checker (o)"""
-    res = {"steps": int(len(o["dts"])), "dts_equal": bool(len(g["dts"]) == len(o["dts"]) and np.allclose(g["dts"], o["dts"], rtol=1e-12, atol=0)),
+    res = {"H_bits_equal": bool(np.array_equal(g["snap"]["H"], o["snap"]["H"])), "Se_bits_equal": bool(np.array_equal(g["snap"]["Se"], o["snap"]["Se"])),
+           "steps": int(len(o["dts"])), "dts_equal": bool(len(g["dts"]) == len(o["dts"]) and np.allclose(g["dts"], o["dts"], rtol=1e-12, atol=0)),
            "rel_H": rel(g["snap"]["H"], o["snap"]["H"]), "abs_Se": float(np.max(np.abs(g["snap"]["Se"] - o["snap"]["Se"]))),
            "scalars": {q: [float(g["snap"][q]), float(o["snap"][q])] for q in ("total_water", "storage", "runoff", "drainage", "lateral")},
            "work_product": {k: int(g["work"][k]) for k in COUNTERS}, "work_checker": {k: int(o["work"][k]) for k in COUNTERS}}

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from criteria3d_amd import capi, catchment as cm
-from tests.tolerances import HEAT_RTOL, WATER_RTOL
+from tests.tolerances import HEAT_RTOL, WATER_RTOL, assert_water_nodes
 
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
@@ -112,8 +112,8 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
             H[mine] = res[f"H_h{h}"][mine]; Se[mine] = res[f"Se_h{h}"][mine]
             np.testing.assert_allclose(res[f"dts_h{h}"], dts, rtol=1e-12)            # identical decisions on every rank
             assert abs(float(res[f"storage_h{h}"]) - snap["storage"]) <= RTOL * abs(snap["storage"])
-        assert np.max(np.abs(H - snap["H"]) / np.maximum(np.abs(snap["H"]), 1e-9)) < RTOL
-        assert np.max(np.abs(Se - snap["Se"])) < RTOL
+        assert_water_nodes(H, snap["H"], f"{case} in {world} strips, hour {h}: H")      # the strips' union holds the single-GPU oracle's bits
+        assert_water_nodes(Se, snap["Se"], f"{case} in {world} strips, hour {h}: Se")
         # boundary sums are reported per rank for its own nodes: they add up to the global ones
         for k in ("runoff", "drainage", "lateral"):
             tot = sum(float(res[f"{k}_h{h}"]) for res in ranks)

@@ -7,7 +7,7 @@ import pytest
 
 from criteria3d_amd import capi, catchment as cm
 from tests.scenarios import ravone_project_model
-from tests.tolerances import WATER_RTOL
+from tests.tolerances import WATER_RTOL, assert_water_nodes
 
 pytestmark = pytest.mark.gpu
 COUNTERS = ("attempts", "accepted", "approximations", "sweeps", "courant_rejections", "linear_failures", "restores")
@@ -17,8 +17,8 @@ def _compare(product, oracle, m, what, base=None):
     """base: (product counters, oracle counters) at the hand-over - the work since then is compared"""
     g, o = cm.snapshot(product, m), cm.snapshot(oracle, m)
     rel = np.max(np.abs(g["H"] - o["H"]) / np.maximum(np.abs(o["H"]), 1e-9))
-    assert rel < WATER_RTOL, (what, rel)
-    assert np.max(np.abs(g["Se"] - o["Se"])) < WATER_RTOL, what
+    assert_water_nodes(g["H"], o["H"], f"{what}: H")
+    assert_water_nodes(g["Se"], o["Se"], f"{what}: Se")
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
         assert abs(g[k] - o[k]) <= WATER_RTOL * max(abs(o[k]), 1e-3), (what, k, g[k], o[k])
     gc, oc = product.counters(), oracle.counters()
@@ -57,6 +57,9 @@ def _check_segment(seg, what, rtol, counters=COUNTERS):
     assert seg["dts_equal"], (what, "accepted dt sequences differ")
     assert seg["rel_H"] < rtol, (what, seg["rel_H"])
     assert seg["abs_Se"] < max(rtol, 1e-9), (what, seg["abs_Se"])
+    from tests.tolerances import WATER_NODES_EXACT
+    if WATER_NODES_EXACT and "rel_T" not in seg:          # water path, default build: the checker's bits in every one of the 5.85 M nodes
+        assert seg["H_bits_equal"] and seg["Se_bits_equal"], (what, seg["rel_H"], seg["abs_Se"])
     for q, (g, o) in seg["scalars"].items():
         assert abs(g - o) <= rtol * max(abs(o), 1e-3), (what, q, g, o)
     for q in counters:
