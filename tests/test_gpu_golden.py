@@ -97,3 +97,31 @@ def test_product_heat_matches_reference_vectors(product, name, compat):
                 assert np.all(np.abs(at[ok] - bt[ok]) <= 2e-6 * scale), (k, t, np.max(np.abs(at[ok] - bt[ok])), scale)
         elif k in ("heat_mbr", "heat_mbe"):
             assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(np.abs(b), 1.0) + (1e-3 if k == "heat_mbe" else 0.0) * 0), (k, a, b)
+
+
+@pytest.mark.parametrize("name", [k for k in HEAT_SCENARIOS if k != "heat_advection_steps"])
+def test_product_heat_in_the_reference_sweep_order_is_the_reference_bit_for_bit(product, name):
+    """The coupled heat step with NOTHING left to differ: SF3D_HEAT_GS=1 sweeps the heat system in the reference's own serial Gauss-Seidel
+    order (level-scheduled, a verification mode ~100 x slower than the default two-colour sweep) and SF3D_COMPAT_STALE_LINK_FLOW=1 mirrors
+    quirk 1; the elementary functions are the C library's in any case.  Temperature, total potential, the thermal conductivities and every
+    boundary flux and conductance of the unmodified reference's vectors must then come out BIT FOR BIT (node values carry no reduction);
+    the sums (storages, balances) to 1e-9; the saved link fluxes, rounded through float by the reference, exactly.  The default sweep order
+    differs from this by the iterative solver's stopping tolerance (test_gpu_heat.py: 1e-9 ... 2.5e-9 in T) - and by nothing else."""
+    from tests.tolerances import WATER_NODES_EXACT
+    if not WATER_NODES_EXACT:
+        pytest.skip("a -DSF3D_LIBM_GLIBC=0 build is being tested")
+    gold = np.load(GOLDEN / f"{name}.npz")
+    with env(SF3D_COMPAT_STALE_LINK_FLOW="1", SF3D_HEAT_GS="1"):
+        trace = run_scenario(product, name, threads=1)
+    assert np.array_equal(trace["steps_per_hour"], gold["steps_per_hour"]) and np.array_equal(np.asarray(trace["dts"]), gold["dts"])
+    report = {}
+    for k in gold.files:
+        a, b = np.asarray(trace[k], float), np.asarray(gold[k], float)
+        assert a.shape == b.shape, k
+        same = bool(np.array_equal(a, b, equal_nan=True))
+        report[k] = same
+        if k.startswith(("T_", "H_", "conductivity_", "boundary_", "flux_")):
+            assert same, (k, int(np.sum(a != b)), float(np.nanmax(np.abs(a - b))))
+        elif k in ("total_water", "storage", "heat_storage"):
+            assert _close(a, b, 1e-9, 1e-9), (k, a, b)
+    print(f"{name}: bit-identical fields {sum(report.values())} of {len(report)}; not identical: {[k for k, v in report.items() if not v]}")
