@@ -75,7 +75,8 @@ def log_ranges(seed=1, n=N):
     rng = np.random.default_rng(seed)
     edges = np.array([0.9375, 1.064697265625, 0.6875, 1.375, 1.0, 2.0, 0.5, 2.2250738585072014e-308, 1.7976931348623157e308, 0.0, -0.0, -1.0,
                       np.inf, -np.inf, np.nan, 5e-324, 1e-310])
-    edges = np.concatenate([edges, np.nextafter(edges, 0), np.nextafter(edges, np.inf)])
+    with np.errstate(over="ignore"):          # (the neighbour of DBL_MAX towards +inf is inf: wanted)
+        edges = np.concatenate([edges, np.nextafter(edges, 0), np.nextafter(edges, np.inf)])
     return {
         "conductivity ratios (the logarithmic mean, otherFunctions.cpp:35)": np.exp(rng.uniform(-3, 3, n)),
         "around one (the polynomial branch)": 1 + rng.uniform(-0.07, 0.07, n),
