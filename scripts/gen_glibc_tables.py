@@ -5,14 +5,16 @@ for the bit-faithful device routines of sf3d_glibcmath.inc.
 
 Why the data comes out of the C library and not out of mpmath alone: the routines are the table designs of Szabolcs Nagy
 (ARM "optimized routines", adopted by glibc 2.28): x = 2^k z, 128 pieces of z, a polynomial in r = z / c - 1.  Which c a piece
-uses was chosen by a search over 2^29 candidates per piece, and the polynomials are minimax fits - neither can be re-derived
+of `log` uses was chosen by a search over 2^29 candidates per piece, and the polynomials are minimax fits - neither can be re-derived
 from the mathematics, and a single different last bit anywhere gives results that are merely "as accurate", not IDENTICAL to
 the library's.  Identical is the point (the config-5 kink window amplifies a last-ulp difference of log / pow to
-7.7e-4), so the 128 x (invc) choices and the polynomial coefficients are READ from the installed library, and everything that
-IS determined by them is re-derived here with mpmath at 200 bits and required to agree with what the library holds:
+7.7e-4), so the 128 centres of `log` and the 27 polynomial coefficients (log 5 + 11, pow 7, exp 4) are READ from the installed
+library; everything else - pow's whole table, exp's whole table, every log c - is DERIVED here with mpmath at 200 bits and required to
+agree with what the library holds:
 
-  log      logc_i                 == RN(-log(invc_i))                         (128 entries)
-  pow      logc_i == -log(invc_i) rounded to a multiple of 2^-43,  logctail_i == RN(-log(invc_i) - logc_i)
+  log      logc_i                 == RN(-log(invc_i))                         (128 entries; invc_i read)
+  pow      invc_i == 1 / centre of piece i rounded to a multiple of 2^-7 (pieces below 1) / 2^-8 (from 1 up);
+           logc_i == -log(invc_i) rounded to a multiple of 2^-43,  logctail_i == RN(-log(invc_i) - logc_i)
   exp      tab[2 i + 1]           == bits(RN(2^(i/128))) - (i << 45),  tab[2 i] == bits(RN(2^(i/128) / H - 1)), H = RN(2^(i/128))
   ln2hi + ln2lo == ln 2 to 2^-90;  InvLn2N == RN(128 / ln 2);  NegLn2hiN + NegLn2loN == -ln 2 / 128 to 2^-100
   cbrt     factor[] == { 1 / RN(2^(2/3)), 1 / RN(2^(1/3)), 1, RN(2^(1/3)), RN(2^(2/3)) } (the quotients rounded once more, as the compiler folds them)
@@ -119,6 +121,14 @@ def read_pow_log(ro: Rodata):
     tab = ro.doubles(off + 72, 4 * N)
     invc, pad, logc, tail = tab[0::4], tab[1::4], tab[2::4], tab[3::4]
     assert all(p == 0.0 for p in pad)
+    # pow's table centres ARE derivable: piece i covers the doubles with bits [OFF + i 2^45, OFF + (i + 1) 2^45), OFF = bits(0x1.69555p-1);
+    # invc_i = 1 / centre rounded to a multiple of 2^-7 for the pieces below 1 and of 2^-8 from 1 up - so few bits that z * invc - 1 is exact
+    off = 0x3FE6955500000000
+    for i in range(N):
+        lo, hi = from_bits(off + (i << 45)), from_bits(off + ((i + 1) << 45))
+        q = 7 if hi <= 1.0 else 8
+        derived = float(mp.nint(mp.mpf(2) ** q / ((mp.mpf(lo) + mp.mpf(hi)) / 2))) / 2 ** q
+        assert derived == invc[i], ("pow_log invc", i, derived, invc[i])
     for i in range(N):
         t = -mp.log(mp.mpf(invc[i]))
         if invc[i] == 1.0:
