@@ -298,3 +298,18 @@ def test_exchange_round_on_one_rank_and_lineal_gate(product):
     assert product.lib.sf3d_set_time_step(120.0) == capi.OK and product.lib.sf3d_get_time_step() == 120.0
     product.lib.sf3d_set_use_lineal(0)
     product.lib.sf3d_clean()
+
+
+def test_dist_queries_without_a_connected_model(product):
+    """the multi-GPU diagnostics and the strip bounds answer sensibly where there is nothing to report (host logic, no device)"""
+    import numpy as np
+    out = np.zeros(32)
+    assert product.lib.sf3d_dist_stats(out.ctypes.data_as(capi.pd), out.size) == capi.MISSING_DATA_ERROR
+    assert product.lib.sf3d_dist_stats(None, 0) == capi.PARAMETER_ERROR
+    b = product.dist_bounds(1000, 3)
+    assert list(b) == [0, 320, 640, 1000] and b.dtype == np.uint32                 # cuts at multiples of 64, the last strip takes the rest
+    assert list(product.dist_bounds(100, 4)) == [0, 0, 0, 64, 100]          # fewer than 64 surface nodes per rank: empty strips are legal
+    bounds = (capi.u32 * 10)()
+    assert product.lib.sf3d_dist_bounds(1000, 0, bounds) == capi.PARAMETER_ERROR and product.lib.sf3d_dist_bounds(1000, 1000, bounds) == capi.PARAMETER_ERROR
+    assert product.lib.sf3d_dist_bounds(1000, 2, None) == capi.PARAMETER_ERROR
+    assert product.lib.sf3d_libm_set() == 1 or "SF3D_PRODUCT_LIB" in __import__("os").environ
