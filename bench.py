@@ -508,7 +508,7 @@ def main():
     # cannot collect counters itself
     traffic, traffic_source, run_traffic = None, None, None
     try:
-        for tag in ("r05_d", "r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
+        for tag in ("r05_q", "r05_d", "r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
             f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
             if not f.exists():
                 continue
@@ -522,7 +522,9 @@ def main():
             break
         if traffic is None and world == 1 and args.workload == "C5" and not args.heat and dom:
             # the Ravone project: PMC passes of `bench.py --workload C5 --steps 1` (the paired sweep runs as k_sweep_pair_masked there)
-            f5 = ROOT / "profiles" / "r05_d_C5_pmc_traffic.json"
+            f5 = ROOT / "profiles" / "r05_q_C5_pmc_traffic.json"
+            if not f5.exists():
+                f5 = ROOT / "profiles" / "r05_d_C5_pmc_traffic.json"
             if not f5.exists():
                 f5 = ROOT / "profiles" / "r03_b_C5_pmc_traffic.json"
             if f5.exists() and not (os.environ.get("SF3D_PRODUCT_LIB") or os.environ.get("SF3D_EXTRA_HIPFLAGS")):
