@@ -2,7 +2,8 @@
 """Expected strong-scaling curve of the headline workload (C4 512 x 512 x 20, F20, the 6-hour episode) at N = 2, 4, 8 GPUs - written
 BEFORE any run on more than one physical GPU, so that the driver's first SCALE record has something to be read against.
 
-Inputs (all measured on ONE MI355X, profiles/r05_c_bench_*.json):
+Inputs (all measured on ONE MI355X; strips: profiles/r05_s_bench_*.json, one box, the gather-free paired sweeps; exchange statistics:
+profiles/r05_c_bench_2ranks_shared.json):
   * T_strip(N): the episode time of one strip of C4 run as a grid of its own (bench.py --workload C4H / C4Q / C4E = one of two / four /
     eight strips; C4 itself for N = 1) - every kernel of the step at the size a rank sees, including whether the paired sweep pays there;
   * E: exchange epochs per episode (sf3d_dist_stats of a two-rank run: one per Jacobi iteration or pair half, per K / waterFlow halo,
@@ -31,8 +32,8 @@ def line(name):
     return json.loads((prof / name).read_text().strip().splitlines()[-1])
 
 
-base = line("r05_a_bench_faithful_libm.json")
-strips = {1: base, 2: line("r05_c_bench_C4H.json"), 4: line("r05_c_bench_C4Q.json"), 8: line("r05_c_bench_C4E.json")}
+base = line("r05_s_bench_C4.json")
+strips = {1: base, 2: line("r05_s_bench_C4H.json"), 4: line("r05_s_bench_C4Q.json"), 8: line("r05_s_bench_C4E.json")}
 two = line("r05_c_bench_2ranks_shared.json")
 E = two["exchange"]["epochs"]                       # per 6-hour episode
 work = base["roofline"]["step"]["work"]
