@@ -254,7 +254,9 @@ struct HeatDev {
  * Per node a 40-bit code, one nibble per link slot: 0..8 = lateral neighbour (dr + 1) * 3 + (dc + 1) of the same layer,
  * 9 = the node above (i - NX NY), 10 = the node below, 15 = no link.  Nodes on the grid's edge fill their lateral slots in
  * their own order (setNodeLink puts the k-th lateral into slot 2 + k), hence a code per node; chunkCode[q] carries the code of
- * chunk q with bit 63 set when all 64 nodes share it (interior), so that the kernel decodes it on the scalar unit. */
+ * chunk q with bit 63 set when all 64 nodes share it (interior), so that the kernel loads it on the scalar unit.  Slot 0 only ever
+ * holds 9 or 15 and slot 1 only 10 or 15 (the host build refuses anything else): the kernels take the vertical neighbours from where
+ * they are by construction and decode only the eight lateral nibbles (bits 8 .. 39). */
 #define SF3D_PAIR_NONE 15u
 #define SF3D_PAIR_UP 9u
 #define SF3D_PAIR_DOWN 10u
