@@ -290,6 +290,8 @@ struct DevView {
      * [0, nListSurf) and its soil part [nListSurf, nList) */
     const uint32_t* chunkList; uint32_t nList, nListSurf;
     const uint32_t* asmList;            /* = chunkList: the order the assembly walks the chunks in */
+    uint32_t pLo, pHi;                  /* the part of the list a launch of k_props walks: [0, nList) unless the approximation is queued in slabs */
+    uint32_t aLo, aHi;                  /* ... a launch of k_assemble's soil blocks: [nListSurf, nList) */
     const uint32_t* bndList; uint32_t nBnd;   /* multi GPU, paired sweep: the owned chunks that read a neighbouring strip (ChunkDesc::pad0): k_sweep_bnd's rows */
     const uint16_t* lmask;      /* bit s: the node has a link in (device) slot s */
     uint32_t haloDirect;                /* multi GPU: the sweeps read foreign neighbours straight from the window and the halo is copied once

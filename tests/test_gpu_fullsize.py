@@ -81,11 +81,12 @@ def _launch_modes(full):
     auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_COURANT_PROBE")}      # the library picks sweep and launch form itself (early Courant check while the Courant number is high)
     modes = [base, auto,
              dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10", SF3D_COURANT_PROBE="always"),     # the paired sweep forced on (small grids too), the early Courant check before every approximation
-             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_OVERLAP_ACCEPT="0")]
+             dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_OVERLAP_ACCEPT="0"),
+             dict(auto, SF3D_SLAB_OVERLAP="3", SF3D_COURANT_PROBE="always")]      # an approximation queued in slabs: rows of one beside the node properties of the next
     if full:
         modes += [fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"),
                   dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0"),
-                  dict(base, SF3D_COURANT_PROBE="always")]
+                  dict(base, SF3D_COURANT_PROBE="always"), dict(fast, SF3D_SLAB_OVERLAP="2", SF3D_GRAPHS="0", SF3D_SLAB_FIRST="0.3")]
     return modes
 
 
