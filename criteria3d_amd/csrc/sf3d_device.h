@@ -253,7 +253,7 @@ struct HeatDev {
 /* ---- paired Jacobi sweep (k_sweep_pair): regular NX x NY x NZ grids in layer-major numbering (one GPU, or one row strip of it) ---
  * Per node a 40-bit code, one nibble per link slot: 0..8 = lateral neighbour (dr + 1) * 3 + (dc + 1) of the same layer,
  * 9 = the node above (i - NX NY), 10 = the node below, 15 = no link.  Nodes on the grid's edge fill their lateral slots in
- * their own order (setNodeLink puts the k-th lateral into slot 2 + k), hence a code per node; chunkCode[q] carries the code of
+ * their own order (setNodeLink puts the k-th lateral into slot 2 + k), hence a code per node (nodeLat); chunkCode[q] carries the code of
  * chunk q with bit 63 set when all 64 nodes share it (interior), so that the kernel loads it on the scalar unit.  Slot 0 only ever
  * holds 9 or 15 and slot 1 only 10 or 15 (the host build refuses anything else): the kernels take the vertical neighbours from where
  * they are by construction and decode only the eight lateral nibbles (bits 8 .. 39). */
@@ -266,8 +266,8 @@ struct PairGrid {
     uint32_t patchCols, patchRows;      /* NX / 64, ceil(NY / (W - 2)) */
     uint32_t ownLo, ownHi;              /* rows [ownLo, ownHi) of the grid are this rank's (0, NY on one GPU); a row beyond them is the halo row of a
                                          * neighbouring strip: its x' comes through the window, the second iteration of the rows next to it is k_sweep_bnd's */
-    const uint64_t* nodeCode;           /* [N] */
-    const uint64_t* chunkCode;          /* [N / 64] */
+    const uint32_t* nodeLat;            /* [N] the eight lateral nibbles of a node's code (bits 8 .. 39) */
+    const uint64_t* chunkCode;          /* [N / 64] the whole code of a chunk whose 64 nodes share it, bit 63 set; 0 otherwise */
     /* layered MASKED grids (k_sweep_pair_masked: DEM outlines, soil columns of different depth): NX x NY x NZ is the bounding grid */
     uint32_t masked;                    /* 1: the fields below describe the graph, chunkCode is unused */
     const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
