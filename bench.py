@@ -535,12 +535,19 @@ def main():
                     traffic_source = f"stored profile profiles/{f5.name} (rocprofv3 --pmc passes of --workload C5 --steps 1; not measured in this run)"
     except Exception:  # noqa: BLE001
         pass
+    if dom == "k_sweep_resident" and stats[dom][0] > 0:
+        # ONE launch = all Jacobi iterations of an approximation, the rows resident on chip: 80 B/node of coefficients + b + z + the starting
+        # iterate once (104 B/node), then 8 B/node stored and ~8 B/node of halo ring read back per iteration (what crosses the CUs)
+        ALGO_BYTES[dom] = 104 + 16 * work["sweeps"] / max(1, work["approximations"] - work["courant_rejections"])
     if dom and stats[dom][0] > 0:
         launches, ms, nodes = stats[dom]
         # (sf3d_kernel_stats reports the nodes THIS rank owns - its strip without the halo - so nothing is divided here)
         avg_s = ms / 1e3 / launches
         achieved = ALGO_BYTES[dom] * nodes / avg_s / 1e9
         note = None
+        if dom == "k_sweep_resident":
+            note = ("one launch = ALL Jacobi iterations of an approximation with the rows resident in registers (csrc/sf3d_resident.inc): bound by the "
+                    "grid barrier between iterations (latency), not by bytes - `frac` prices the little it still moves")
         if dom == "k_sweep_pair":
             note = ("one pass = two Jacobi iterations: `frac` prices the 160 B/node the pass moves; `equivalent_sweep_frac` prices the two "
                     "single sweeps it replaces (2 x 152 B/node, SURVEY 8d) and is a speed-up measure, not a bandwidth fraction")
@@ -556,7 +563,8 @@ def main():
         # SURVEY 8d's model with the work counters of one 6-hour episode over the median episode time (K < 6: the whole timed region)
         paired = stats.get("k_sweep_pair", (0,))[0] > 0
         n_rank = model.n // split
-        b_j = 80 if paired else 152
+        resident = stats.get("k_sweep_resident", (0,))[0] > 0
+        b_j = 80 if paired else (16 if resident else 152)
         w_, el_, what = (episode_work, elapsed_6h, "one 6-hour episode (hours 0-5)") if episode_work and elapsed_6h else (work, elapsed, f"the {args.steps} timed hours")
         n_a = w_["approximations"] - w_.get("early_courant_rejections", 0)      # (an attempt the early Courant check refused moved next to nothing)
         step_bytes = n_rank * (b_j * w_["sweeps"] + B_APPROX * n_a + B_STEP * w_["accepted"] + B_RESTORE * w_["restores"])

@@ -147,8 +147,9 @@ struct Ctrl {
     double cgRho, cgAlpha, cgBeta, cgBnorm2, cgRes2;
     uint32_t seqCount, seqSweeps[16];   /* Jacobi iterations of the 1st, 2nd, ... approximation of the computeStep in progress (0 for one the Courant check
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
-    uint32_t barGen;          /* persistent step kernel: value the grid-barrier counter had when the last launch ended */
+    uint32_t barGen;          /* resident sweep loop: grid barriers passed so far (the counters of ResGrid::bar are monotonic: the next launch starts from here) */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
+    uint64_t residentLaunches;  /* k_sweep_resident launches that really ran (one per approximation: all its Jacobi iterations) */
     /* paired sweep on a strip (multi GPU): k_sweep_pair leaves the second iteration of the rows next to a neighbouring strip to
      * k_sweep_bnd, which needs the neighbours' first iterate: pending = 1 between the two launches, x'' goes to pool buffer pairX2 and
      * the (all-gathered) second norm of the rows k_sweep_pair did itself waits in pairNorm2 */
@@ -278,6 +279,25 @@ struct PairGrid {
                                          * put there, second iteration in k_sweep_bnd.  null on one GPU */
 };
 
+/* ---- resident-coefficient sweep loop (k_sweep_resident, sf3d_resident.inc): a regular grid (one GPU) or one row strip of it whose rows
+ * fit on chip - every block keeps the normalised rows of its patch (PR rows x 64 columns x NZ layers) in registers for ALL the Jacobi
+ * iterations of an approximation, the iterate of the patch and its one-cell halo in an LDS tile; iterations are separated by a grid
+ * barrier (all blocks co-resident: the host sizes the grid from the occupancy query) that also carries the norm. */
+struct ResGrid {
+    uint32_t on;                        /* 0: this graph / grid does not fit (the sweeps are separate launches then) */
+    uint32_t NX, NY, NZ;                /* the (rank-local) grid */
+    uint32_t PR;                        /* rows of a block's patch */
+    uint32_t patchCols, rowGroups;      /* NX / 64, ceil(owned rows / PR): blocks = patchCols * rowGroups, one (or two) per CU */
+    uint32_t ownLo, ownHi;              /* rows [ownLo, ownHi) are this rank's (0, NY on one GPU) */
+    uint32_t K, NW;                     /* (row, layer) chunks a wave keeps, waves of a block: PR * NZ <= K * NW */
+    const uint32_t* nodeLat;            /* [N] the eight lateral nibbles of a node's code (PairGrid) */
+    const uint64_t* chunkCode;          /* [N / 64] */
+    unsigned int* bar;                  /* arrival counters of the grid barrier, monotonic, one 128-B line each: [0] top, [1 .. 16] shards, [17] release (multi GPU) */
+    double* pub;                        /* multi GPU: [2][4] what the leading block publishes after the all-gather of an iteration (norm hi, lo, status) */
+    const uint32_t* haloSrc;            /* multi GPU: [2 sides][NZ][NX] where the value of a cell of the foreign halo row above (side 0) / below (1) arrives
+                                         * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
+};
+
 struct DevView {
     uint32_t N, ns, nb;                 /* nodes, surface nodes, blocks of SF3D_BLOCK threads */
     uint32_t Nnorm;                     /* node count the mean norm of a sweep divides by: N, or the global count for a strip-local model */
@@ -339,11 +359,12 @@ struct DevView {
     const SoilDev* soils;
     const double* roughness;
     PairGrid pair;
+    ResGrid res;
     Ctrl* ctrl;
     HeatDev heat;
 };
 
 /* kernels instrumented by sf3d_kernel_timing (ids index the arrays in the solver) */
-enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_COUNT };
+enum { KID_PROPS = 0, KID_ASSEMBLE, KID_SWEEP, KID_POST, KID_RESTORE, KID_ACCEPT, KID_SWEEP_PAIR, KID_SWEEP_RES, KID_COUNT };
 
 #endif
