@@ -143,6 +143,7 @@ SIGNATURES = {
     "sf3d_device_cbrt": (u8, [u32, pd, pd]),
     "sf3d_device_norm_sum": (u8, [u32, pd, u32, i32, pd]),
     "sf3d_get_sweep_launches": (u8, [p64, p64]),
+    "sf3d_get_resident_launches": (u8, [p64]),
     "sf3d_get_heat_counters": (u8, [p64]),
     "sf3d_device_pow": (u8, [u32, pd, pd, pd]),
     "sf3d_device_bytes": (u64, []),
@@ -307,6 +308,12 @@ class SF3D:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self.check(self.lib.sf3d_get_sweep_launches(C.byref(a), C.byref(b)), "get_sweep_launches")
         return int(a.value), int(b.value)
+
+    def resident_launches(self):
+        """resident sweep loops (all Jacobi iterations of an approximation in one launch) since sf3d_initialize"""
+        a = C.c_uint64(0)
+        self.check(self.lib.sf3d_get_resident_launches(C.byref(a)), "get_resident_launches")
+        return int(a.value)
 
     # -- multi-GPU bootstrap -----------------------------------------------------------------
     def dist_connect(self, rank, world, allgather):

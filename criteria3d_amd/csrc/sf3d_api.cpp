@@ -957,6 +957,12 @@ sf3d_error_t sf3d_get_sweep_launches(uint64_t* single, uint64_t* paired)
     *single = dev().ready() ? c.singleLaunches : 0; *paired = dev().ready() ? c.pairLaunches : 0;
     return SF3D_OK;
 }
+sf3d_error_t sf3d_get_resident_launches(uint64_t* loops)
+{
+    if (!loops) return SF3D_PARAMETER_ERROR;
+    *loops = dev().ready() ? dev().ctrl().residentLaunches : 0;
+    return SF3D_OK;
+}
 sf3d_error_t sf3d_get_heat_counters(uint64_t out[4])
 {
     if (!out) return SF3D_PARAMETER_ERROR;

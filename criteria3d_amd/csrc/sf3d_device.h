@@ -147,7 +147,7 @@ struct Ctrl {
     double cgRho, cgAlpha, cgBeta, cgBnorm2, cgRes2;
     uint32_t seqCount, seqSweeps[16];   /* Jacobi iterations of the 1st, 2nd, ... approximation of the computeStep in progress (0 for one the Courant check
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
-    uint32_t barGen;          /* resident sweep loop: grid barriers passed so far (the counters of ResGrid::bar are monotonic: the next launch starts from here) */
+    uint32_t barGen;          /* (unused) */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
     uint64_t residentLaunches;  /* k_sweep_resident launches that really ran (one per approximation: all its Jacobi iterations) */
     /* paired sweep on a strip (multi GPU): k_sweep_pair leaves the second iteration of the rows next to a neighbouring strip to
@@ -217,8 +217,8 @@ struct DistView {
  * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate
  * fields because the x of the LAST sweep of an approximation is consumed late (by the readers' k_post), after a fast
  * neighbour may already have put the K of the next approximation into the same parity. */
-#define SF3D_DIST_FIELDS 3
-enum { DF_X = 0, DF_K = 1, DF_FLOW = 2 };
+#define SF3D_DIST_FIELDS 5
+enum { DF_X = 0, DF_K = 1, DF_FLOW = 2, DF_RECLO = 3, DF_RECHI = 4 };      /* (3, 4: the iterate as tagged records, for the resident sweep loop's in-launch hand-off - sf3d_resident.inc) */
 #define SF3D_FSRC_NONE 0xFFFFFFFFu      /* fsrc: (source rank << 27) | position in that rank's send list */
 
 /* coupled heat transport (heat.cpp): everything the heat kernels and the heat terms of the water kernels
@@ -292,8 +292,11 @@ struct ResGrid {
     uint32_t K, NW;                     /* (row, layer) chunks a wave keeps, waves of a block: PR * NZ <= K * NW */
     const uint32_t* nodeLat;            /* [N] the eight lateral nibbles of a node's code (PairGrid) */
     const uint64_t* chunkCode;          /* [N / 64] */
-    unsigned int* bar;                  /* arrival counters of the grid barrier, monotonic, one 128-B line each: [0] top, [1 .. 16] shards, [17] release (multi GPU) */
-    double* pub;                        /* multi GPU: [2][4] what the leading block publishes after the all-gather of an iteration (norm hi, lo, status) */
+    unsigned int* bar;                  /* [0] iterations of all launches so far: the tag base of the records below */
+    unsigned long long* rec;            /* [2 parities][2 halves][N] the new iterate as tagged records (a double = two words {32 data bits, 32-bit tag}) */
+    unsigned long long* prec;           /* [2][4][blocks] the blocks' partial norms ((hi, lo) x two halves) */
+    unsigned long long* gpub;           /* [2][4] multi GPU: the all-gathered norm, published by block 0 */
+    double* pub;                        /* tuning builds (SF3D_RES_PROFILE): phase timers of block 0 */
     const uint32_t* haloSrc;            /* multi GPU: [2 sides][NZ][NX] where the value of a cell of the foreign halo row above (side 0) / below (1) arrives
                                          * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
 };

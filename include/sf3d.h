@@ -318,6 +318,10 @@ sf3d_error_t sf3d_get_counters(uint64_t out[8]);
  * run: the pass + its boundary launch count as one).  Implementation detail of the product - no result depends on it; the CPU
  * libraries return SF3D_MISSING_DATA_ERROR. */
 sf3d_error_t sf3d_get_sweep_launches(uint64_t* single_sweeps, uint64_t* paired_passes);
+/* ... and RESIDENT loops: launches that made ALL Jacobi iterations of an approximation with the rows kept on chip (grids that fit:
+ * csrc/sf3d_resident.inc; neither of the two counts above moves then).  Same status: an implementation detail, SF3D_MISSING_DATA_ERROR
+ * from the CPU libraries. */
+sf3d_error_t sf3d_get_resident_launches(uint64_t* resident_loops);
 /* Work counters of the heat part since sf3d_initialize (heatLoop, cpusolver.cpp:471-605; computeStep's heat loop,
  * soilFluxes3D.cpp:1802-1818): out[0] heat steps accepted (heatLoop returned true), [1] heat steps halved (|MBR| > 1: false),
  * [2] reductions of dtHeat by the boundary Courant rule (updateBoundaryHeatData returned false, heat.cpp:329-339),

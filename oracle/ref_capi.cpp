@@ -181,6 +181,7 @@ sf3d_error_t sf3d_device_exp(uint32_t, const double*, double*) { return SF3D_MIS
 sf3d_error_t sf3d_device_cbrt(uint32_t, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_norm_sum(uint32_t, const double*, uint32_t, int, double*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_get_sweep_launches(uint64_t*, uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
+sf3d_error_t sf3d_get_resident_launches(uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_get_heat_counters(uint64_t*) { return SF3D_MISSING_DATA_ERROR; }
 sf3d_error_t sf3d_device_pow(uint32_t, const double*, const double*, double*) { return SF3D_MISSING_DATA_ERROR; }
 

@@ -28,6 +28,8 @@ if case == "c2f20":
     m, plan = cm.catchment_model(64, 64, 10), [20.0, 0.0]
 elif case == "c2f60":
     m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
+elif case == "het64":            # twelve soils on a grid the regular-grid sweeps accept (64 columns), cut into strips of 16 rows
+    m, plan = cm.catchment_model(64, 64, 6, heterogeneous=True), [20.0, (0.0, 100)]
 elif case == "het":
     m, plan = cm.catchment_model(48, 40, 6, heterogeneous=True), [20.0, (0.0, 150)]
 elif case == "ragged":
@@ -94,7 +96,7 @@ res["device_bytes"] = np.array(int(sf.lib.sf3d_device_bytes()), dtype=np.int64)
 res["host_bytes_end"] = np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
-res["sweep_launches"] = np.array(sf.sweep_launches(), dtype=np.int64)          # (single sweeps, paired passes) of this rank
+res["sweep_launches"] = np.array(sf.sweep_launches() + (sf.resident_launches(),), dtype=np.int64)          # (single sweeps, paired passes, resident loops) of this rank
 np.savez(outfile, **res)
 dist.barrier()
 sf.lib.sf3d_clean()

@@ -76,15 +76,15 @@ def _launch_modes(full):
     """The reference point is the plain path: separate decision kernels, eager launches, link sums inside the step, single sweeps.
     Against it: the defaults a user gets (fused decisions, hipGraphs, overlapped link sums and - where the grid is large - the
     paired sweep), and every switchable form on its own."""
-    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_COURANT_PROBE="0")
-    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_COURANT_PROBE="0")
-    auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_COURANT_PROBE")}      # the library picks sweep and launch form itself (early Courant check while the Courant number is high)
-    modes = [base, auto,
+    base = dict(SF3D_FUSED_DECIDE="0", SF3D_GRAPHS="0", SF3D_OVERLAP_ACCEPT="0", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_COURANT_PROBE="0", SF3D_RESIDENT_SWEEP="0")
+    fast = dict(SF3D_FUSED_DECIDE="1", SF3D_GRAPHS="1", SF3D_OVERLAP_ACCEPT="1", SF3D_RESIDENT_GRIDS="1", SF3D_PAIR_SWEEP="0", SF3D_COURANT_PROBE="0", SF3D_RESIDENT_SWEEP="0")
+    auto = {k: v for k, v in fast.items() if k not in ("SF3D_PAIR_SWEEP", "SF3D_COURANT_PROBE", "SF3D_RESIDENT_SWEEP")}      # the library picks sweep and launch form itself (early Courant check while the Courant number is high; the resident sweep loop where the rows of the grid fit on chip: C2)
+    modes = [base, auto, fast,      # (fast: fused single sweeps from hipGraphs - what `auto` runs where neither the resident loop nor the paired pass applies)
              dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="10", SF3D_COURANT_PROBE="always"),     # the paired sweep forced on (small grids too), the early Courant check before every approximation
              dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="6", SF3D_OVERLAP_ACCEPT="0"),
              dict(auto, SF3D_SLAB_OVERLAP="3", SF3D_COURANT_PROBE="always")]      # an approximation queued in slabs: rows of one beside the node properties of the next
     if full:
-        modes += [fast, dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"),
+        modes += [dict(fast, SF3D_OVERLAP_ACCEPT="0"), dict(fast, SF3D_RESIDENT_GRIDS="0"), dict(auto, SF3D_RESIDENT_SWEEP="1", SF3D_GRAPHS="0"),
                   dict(fast, SF3D_PAIR_SWEEP="1", SF3D_PAIR_W="14", SF3D_GRAPHS="0"),
                   dict(base, SF3D_COURANT_PROBE="always"), dict(fast, SF3D_SLAB_OVERLAP="2", SF3D_GRAPHS="0", SF3D_SLAB_FIRST="0.3")]
     return modes
@@ -99,7 +99,7 @@ def _run_modes(case, modes, tmp_path):
     outs = []
     for k, mode in enumerate(modes):
         out = tmp_path / f"{case}_{k}.npz"
-        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM"))}
+        env = {kk: vv for kk, vv in os.environ.items() if not kk.startswith(("SF3D_PAIR", "SF3D_ASM", "SF3D_RESIDENT"))}
         env.update(mode)
         p = subprocess.run([sys.executable, str(root / "scripts" / "run_case.py"), case, str(out)], env=env,
                            capture_output=True, text=True, timeout=900)

@@ -95,7 +95,7 @@ def test_sharded_run_matches_oracle(oracle, tmp_path, world, case, port):
     if pair_env:
         assert all(int(res["sweep_launches"][1]) > 0 for res in ranks), [res["sweep_launches"] for res in ranks]
     if case == "c4f20h0" and world == 2:      # (eight strips: against the oracle only - sixteen rank processes of C4 are 25 s of model building)
-        single = run_ranks(world, case, tmp_path, port + 20, env={"SF3D_PAIR_SWEEP": "0"})
+        single = run_ranks(world, case, tmp_path, port + 20, env={"SF3D_PAIR_SWEEP": "0", "SF3D_RESIDENT_SWEEP": "0"})
         assert all(int(res["sweep_launches"][1]) == 0 for res in single)
         own = ranks[0]["owner"]
         for r in range(world):
@@ -144,7 +144,7 @@ def test_paired_sweep_on_strips_is_bitwise_the_single_sweeps(tmp_path, world, ca
     holes, a window of the Ravone project: strips cut mid-row), strip-local models and the global-index checker mode: every
     owned node's H and Se, every accepted dt and every work counter equal to the run with single sweeps; paired passes on every rank"""
     pair = run_ranks(world, case, tmp_path, port, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6", "SF3D_DIST_LOCAL": local})
-    single = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_PAIR_SWEEP": "0", "SF3D_DIST_LOCAL": local})
+    single = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_PAIR_SWEEP": "0", "SF3D_RESIDENT_SWEEP": "0", "SF3D_DIST_LOCAL": local})
     owner = pair[0]["owner"]
     for r in range(world):
         assert int(pair[r]["sweep_launches"][1]) > 0 and int(single[r]["sweep_launches"][1]) == 0, (r, pair[r]["sweep_launches"])
@@ -154,6 +154,26 @@ def test_paired_sweep_on_strips_is_bitwise_the_single_sweeps(tmp_path, world, ca
                 assert np.array_equal(pair[r][k][mine], single[r][k][mine]), (r, k)
             elif k.startswith("dts_h") or k == "counters":
                 assert np.array_equal(pair[r][k], single[r][k]), (r, k)
+
+
+@pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29671, "1"), (4, "c2f60", 29673, "1"), (2, "c2f60", 29675, "0"), (4, "het64", 29677, "1")])
+def test_resident_sweep_loop_on_strips_is_bitwise_the_single_sweeps(tmp_path, world, case, port, local):
+    """k_sweep_resident<DIST> (csrc/sf3d_resident.inc: all Jacobi iterations of an approximation in one launch; the edge rows hand their
+    new iterate to the neighbouring rank as tagged records in its window, block 0 all-gathers the norm once per iteration) against
+    single sweeps on the same strips: infiltration and runoff regime, strip-local models and the global-index checker mode, two and
+    four ranks - every owned node's H and Se, every accepted dt, every work counter and the number of exchange epochs"""
+    res = run_ranks(world, case, tmp_path, port, env={"SF3D_RESIDENT_SWEEP": "1", "SF3D_PAIR_SWEEP": "0", "SF3D_DIST_LOCAL": local})
+    single = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_RESIDENT_SWEEP": "0", "SF3D_PAIR_SWEEP": "0", "SF3D_DIST_LOCAL": local})
+    owner = res[0]["owner"]
+    for r in range(world):
+        assert int(res[r]["sweep_launches"][2]) > 0 and int(res[r]["sweep_launches"][0]) == 0, (r, res[r]["sweep_launches"])
+        assert int(single[r]["sweep_launches"][2]) == 0 and int(single[r]["sweep_launches"][0]) > 0, (r, single[r]["sweep_launches"])
+        mine = owner == r
+        for k in res[r].files:
+            if k.startswith(("H_h", "Se_h")):
+                assert np.array_equal(res[r][k][mine], single[r][k][mine]), (r, k)
+            elif k.startswith("dts_h") or k == "counters":
+                assert np.array_equal(res[r][k], single[r][k]), (r, k)
 
 
 @pytest.mark.parametrize("world,case,port", [(3, "c2f60", 29641), (2, "ragged", 29643), (3, "random", 29645)])
