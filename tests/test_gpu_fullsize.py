@@ -165,7 +165,7 @@ def test_paired_sweep_on_awkward_grids(product, shape, w):
     m = cm.catchment_model(nx, ny, nz)
     res = []
     for pair in ("0", "1"):
-        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w, SF3D_RESIDENT_SWEEP="0"):      # (single sweeps as launches of their own: the resident loop has tests/test_gpu_resident.py)
             product.check(product.lib.sf3d_reset_solver_state(), "reset")
             cm.build(product, m)
             product.check(product.lib.sf3d_kernel_timing(1), "timing")       # event statistics tell which sweep kernel ran
@@ -202,7 +202,7 @@ def test_paired_sweep_on_masked_grids(product, which, w):
     assert m.ns >= 64
     res = []
     for pair in ("0", "1"):
-        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w, SF3D_PAIR_FORCE_MASKED="1" if which == "full_box" else "0"):
+        with env(SF3D_PAIR_SWEEP=pair, SF3D_PAIR_W=w, SF3D_PAIR_FORCE_MASKED="1" if which == "full_box" else "0", SF3D_RESIDENT_SWEEP="0"):
             product.check(product.lib.sf3d_reset_solver_state(), "reset")
             cm.build(product, m)
             product.check(product.lib.sf3d_kernel_timing(1), "timing")       # event statistics tell which sweep kernel ran
