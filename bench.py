@@ -56,6 +56,23 @@ EQUIVALENT_SWEEP_BYTES = {"k_sweep_pair": 2 * 152}
 # whole-step model of SURVEY.md 8d: bytes = N (B_J n_J + 441 n_A + 336 n_S + 117 n_R); with the paired sweep a Jacobi iteration
 # costs half a pass (80 B/node)
 B_APPROX, B_STEP, B_RESTORE = 441, 336, 117
+# coupled heat transport (csrc/sf3d_heat.inc; latent heat on, no advection, no flux saving - the configuration of config 5), bytes per SOIL
+# node, each array counted once per kernel (neighbour gathers of an array the node itself reads are cache hits):
+#   per heat sub-step  k_heat_boundary 32 (heatSink, btype, heatFlux; the atmosphere / fixed-temperature terms of the top and bottom layer averaged over
+#                      the column) + k_heat_props 122 (cls, z, T, Told, H, Hold, size, airP, thetaOld, the two cached water contents; hC, kHeat, hAvg,
+#                      kIsoVap, hcapTerm out) + k_heat_assemble 248 (T, Told, kHeat, hAvg, kIsoVap, ten link distances, hC, hcapTerm, heatFlux; the
+#                      row 80, diagonal, rhs, invariant out) + k_heat_post 58 (heatFlux, cls, H, Hold, size, T, z, thNewC)            = 460
+#   per heat sweep     both colour halves together touch every node once: the row 80 + rhs + diagonal + colour + iterate in / out   = 113
+#   per computeStep    k_heat_save_water_props 34 (H, z, cls -> thetaOld)
+#   per approximation  the water kernels' heat terms: k_props<heat> + 40 (T, Told; three thermal conductivities out), k_assemble<heat> + 32
+B_HEAT_STEP, B_HEAT_SWEEP, B_HEAT_CSTEP, B_HEAT_APPROX_EXTRA = 460, 113, 34, 72
+
+
+def heat_bytes(n_soil, heat_work, water_work):
+    """bytes the heat part of the counted work has to move (the model above)"""
+    n_steps = heat_work["accepted"] + heat_work["halved"]
+    return n_soil * (B_HEAT_STEP * n_steps + B_HEAT_SWEEP * heat_work["sweeps"] + B_HEAT_CSTEP * water_work["accepted"]
+                     + B_HEAT_APPROX_EXTRA * (water_work["approximations"] - water_work.get("early_courant_rejections", 0)))
 
 
 def log(*a):
@@ -159,6 +176,17 @@ def rewind_to_initial(sf, capi, model, heat):
 def strip_checksums(H, owner, world):
     import zlib
     return [int(zlib.crc32(np.ascontiguousarray(H[owner == r]).tobytes())) for r in range(world)]
+
+
+def csrc_fingerprint():
+    """fingerprint of the kernels' sources (the same rule as scripts/profile_summary.py): a stored PMC profile is only quoted as THIS
+    build's traffic when it was taken on the same sources"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "criteria3d_amd" / "csrc").iterdir()):
+        if f.suffix in (".inc", ".h", ".hip", ".cpp"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_model_name():
@@ -474,7 +502,7 @@ def main():
 
     reps = max(1, args.reps) if args.reps > 0 else 3          # --reps 0: at least 3, and as many as it takes to time >= 1.5 s (<= 15)
     rep_elapsed, rep_incl, rep_episodes, episode_work = [], [], [], None      # (rep_episodes: every complete 6-hour episode of every repetition)
-    per_step, hour_starts, c0, work0 = [], [], None, None
+    per_step, hour_starts, c0, work0, heat_work0 = [], [], None, None, None
     rep = 0
     while rep < reps:
         if rep > 0:
@@ -484,12 +512,16 @@ def main():
         barrier()
         torch.cuda.synchronize()
         cb = sf.counters()
+        hcb = sf.heat_counters() if heat is not None else None
         el = run_hours(sf, cm, model, args.forcing, args.steps, per_step=ps, hour_starts=hs_, heat=heat, per_hour=ph, inclusive=incl,
                        rewind=rewind, counters_at=cat, after_hour=grab_episode_end if rep == 0 else None)
         torch.cuda.synchronize()
         ca = sf.counters()
         did = {k: ca[k] - cb[k] for k in ca}
         if rep == 0:
+            if heat is not None:
+                hca = sf.heat_counters()
+                heat_work0 = {k: hca[k] - hcb[k] for k in hca}
             c0, c1, work0 = cb, ca, did
             stats = sf.kernel_stats()
             per_step, hour_starts = ps, hs_
@@ -601,6 +633,8 @@ def main():
                     rewind_to_initial(sf, capi, m2, heat2)
                 sf.check(sf.lib.sf3d_kernel_timing(2 if r2 == 0 else 0), "kernel_timing")
                 cb2 = sf.counters()
+                if r2 == 0 and heat2 is not None:
+                    hc0 = sf.heat_counters()
                 t2 = 0.0
                 for h2, mm2 in enumerate(hours_plan):
                     sf.set_sink_source_bulk(0, np.full(m2.ns, cm.rain_rate(mm2, m2.cell_area)))
@@ -635,10 +669,21 @@ def main():
                     b2 = 104 + 16 * w2["sweeps"] / max(1, w2["approximations"] - w2["courant_rejections"])
                 dk = {"kernel": d2, "launches": n2, "avg_us": ms2 / n2 * 1e3, "algorithmic_bytes_per_launch": b2 * nodes2,
                       "frac": b2 * nodes2 / (ms2 / n2 / 1e3) / 1e9 / HBM_PEAK_GBS}
-            legs[name] = {"value": len(hours_plan) / tm, "unit": "sim-h/s", "hours": len(hours_plan), "elapsed_s": tm, "repeats_s": times, "nodes": m2.n,
-                          "ms_per_computeStep": tm / max(1, w2["accepted"]) * 1e3, "work": w2, "dominant_kernel": dk, "build_s": t_b, "workload": what}
+            paired2 = st2.get("k_sweep_pair", (0,))[0] > 0
+            resident2 = st2.get("k_sweep_resident", (0,))[0] > 0
+            bj2 = 80 if paired2 else (16 if resident2 else 152)
+            na2 = w2["approximations"] - w2.get("early_courant_rejections", 0)
+            sb2 = m2.n * (bj2 * w2["sweeps"] + B_APPROX * na2 + B_STEP * w2["accepted"] + B_RESTORE * w2["restores"])
+            hw2 = None
             if heat2 is not None:
-                legs[name]["heat_work"] = sf.heat_counters()
+                hc1 = sf.heat_counters()
+                hw2 = {k: hc1[k] - hc0[k] for k in hc1}
+                sb2 += heat_bytes(m2.n - m2.ns, hw2, w2)
+            legs[name] = {"step": {"bytes": sb2, "frac": sb2 / tm / 1e9 / HBM_PEAK_GBS,
+                                   "model": f"N ({bj2} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R)" + (f" + N_soil ({B_HEAT_STEP} heat sub-steps + {B_HEAT_SWEEP} heat sweeps + {B_HEAT_CSTEP} n_S + {B_HEAT_APPROX_EXTRA} n_A)" if hw2 else ""), "heat_work": hw2},
+                          "value": len(hours_plan) / tm, "unit": "sim-h/s", "hours": len(hours_plan), "elapsed_s": tm, "repeats_s": times, "nodes": m2.n,
+                          "ms_per_computeStep": tm / max(1, w2["accepted"]) * 1e3, "work": w2, "dominant_kernel": dk, "build_s": t_b, "workload": what}
+
             log(f"[bench] leg {name}: {legs[name]['value']:.4f} sim-h/s ({tm:.2f} s, build {t_b:.1f} s)")
 
         try:
@@ -658,9 +703,16 @@ def main():
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs
     # of this same command, corrected per MI355X_MICROARCH.md: 2 x FETCH_SIZE + WRITE_SIZE); bench.py
     # cannot collect counters itself
-    traffic, traffic_source, run_traffic = None, None, None
+    traffic, traffic_source, run_traffic, traffic_current = None, None, None, None
     try:
-        for tag in ("r05_q", "r05_d", "r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
+        here = csrc_fingerprint()
+
+        def stamp(prof_json, name, what):
+            sha = prof_json.get("source_sha16")
+            same = sha == here
+            return (f"stored profile profiles/{name} ({what}; not measured in this run); "
+                    + ("taken on exactly these kernel sources" if same else f"TAKEN ON OTHER KERNEL SOURCES (profile {sha or 'unstamped: before round 6'}, this build {here}): an indication, not this build's traffic")), same
+        for tag in ("r06_z", "r06_c", "r05_q", "r05_d", "r04_d", "r04_b", "r03_b", "r03_a", "r02_c", "r02_b", "r02_a", "r01_k"):
             f = ROOT / "profiles" / f"{tag}_kernel_summary.json"
             if not f.exists():
                 continue
@@ -670,11 +722,13 @@ def main():
                 traffic = prof[dom]["hbm_traffic_MB"] * 1e6
                 if args.steps >= EPISODE_HOURS and prof.get("whole_run", {}).get("steps") == EPISODE_HOURS and args.forcing == "F20":
                     run_traffic = prof["whole_run"]["hbm_traffic_GB"] * 1e9      # counted traffic of one 6-hour episode
-                traffic_source = f"stored profile profiles/{f.name} (rocprofv3 --pmc passes of this command; not measured in this run)"
+                traffic_source, traffic_current = stamp(prof, f.name, "rocprofv3 --pmc passes of this command")
             break
         if traffic is None and world == 1 and args.workload == "C5" and not args.heat and dom:
             # the Ravone project: PMC passes of `bench.py --workload C5 --steps 1` (the paired sweep runs as k_sweep_pair_masked there)
-            f5 = ROOT / "profiles" / "r05_q_C5_pmc_traffic.json"
+            f5 = ROOT / "profiles" / "r06_z_C5_pmc_traffic.json"
+            if not f5.exists():
+                f5 = ROOT / "profiles" / "r05_q_C5_pmc_traffic.json"
             if not f5.exists():
                 f5 = ROOT / "profiles" / "r05_d_C5_pmc_traffic.json"
             if not f5.exists():
@@ -684,7 +738,7 @@ def main():
                 k5 = "k_sweep_pair_masked" if dom == "k_sweep_pair" else dom
                 if k5 in p5 and "hbm_traffic_MB" in p5[k5]:
                     traffic = p5[k5]["hbm_traffic_MB"] * 1e6
-                    traffic_source = f"stored profile profiles/{f5.name} (rocprofv3 --pmc passes of --workload C5 --steps 1; not measured in this run)"
+                    traffic_source, traffic_current = stamp(p5, f5.name, "rocprofv3 --pmc passes of --workload C5 --steps 1")
     except Exception:  # noqa: BLE001
         pass
     if dom == "k_sweep_resident" and stats[dom][0] > 0:
@@ -704,7 +758,7 @@ def main():
             note = ("one pass = two Jacobi iterations: `frac` prices the 160 B/node the pass moves; `equivalent_sweep_frac` prices the two "
                     "single sweeps it replaces (2 x 152 B/node, SURVEY 8d) and is a speed-up measure, not a bandwidth fraction")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_is_of_this_build": traffic_current,
                     "traffic_frac": (traffic / avg_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                     "launches": launches, "avg_us": avg_s * 1e6, "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * nodes,
                     "note": note,
@@ -721,7 +775,13 @@ def main():
         n_a = w_["approximations"] - w_.get("early_courant_rejections", 0)      # (an attempt the early Courant check refused moved next to nothing)
         step_bytes = n_rank * (b_j * w_["sweeps"] + B_APPROX * n_a + B_STEP * w_["accepted"] + B_RESTORE * w_["restores"])
         survey_bytes = n_rank * (152 * w_["sweeps"] + B_APPROX * n_a + B_STEP * w_["accepted"] + B_RESTORE * w_["restores"])
-        roofline["step"] = {"bytes": step_bytes, "elapsed_s": el_, "achieved": step_bytes / el_ / 1e9, "unit": "GB/s",
+        hb = 0
+        if heat is not None and heat_work0 is not None and w_ is work:
+            hb = heat_bytes(model.n - model.ns, heat_work0, work)
+            step_bytes += hb; survey_bytes += hb
+        roofline["step"] = {"heat_bytes": hb or None, "heat_work": heat_work0 if hb else None,
+                            "heat_model": (f"+ N_soil ({B_HEAT_STEP} heat sub-steps + {B_HEAT_SWEEP} heat sweeps + {B_HEAT_CSTEP} computeSteps + {B_HEAT_APPROX_EXTRA} approximations)" if hb else None),
+                            "bytes": step_bytes, "elapsed_s": el_, "achieved": step_bytes / el_ / 1e9, "unit": "GB/s",
                             "frac": step_bytes / el_ / 1e9 / HBM_PEAK_GBS, "region": what, "work": w_,
                             "model": f"N ({b_j} n_J + {B_APPROX} n_A + {B_STEP} n_S + {B_RESTORE} n_R) per rank, counters of {what}"
                                      + (" (a Jacobi iteration inside a paired pass costs 80 B/node)" if paired else ""),

@@ -364,7 +364,8 @@ template <class T> void reset(std::vector<T>& v, size_t n) { v.assign(n, T()); }
 #define NEED_NODE_E(i) if ((i) >= M.N) return SF3D_INDEX_ERROR
 #define NEED_INIT_D   if (!M.initialized) return errValue(SF3D_MEMORY_ERROR)
 /* (a node of another rank's strip once the staging copy is trimmed: NODATA, like the bulk getters - sf3d_dist_owner says whose it is) */
-#define NEED_NODE_D(i) if ((i) >= M.N) return errValue(SF3D_INDEX_ERROR); if (skippedByTrim(i)) return (double)SF3D_NODATA
+/* (ONE statement - an else-if chain closed by an empty else - so that it stays whole under an unbraced if) */
+#define NEED_NODE_D(i) if ((i) >= M.N) return errValue(SF3D_INDEX_ERROR); else if (skippedByTrim(i)) return (double)SF3D_NODATA; else (void)0
 
 }  // namespace
 

@@ -117,6 +117,8 @@ struct Ctrl {
                                array (k_post / k_restore of the accepted step), 2 SeHold (the refused attempt started from the same H) */
     uint32_t epoch;         /* exchange counter, identical on every rank (multi-GPU) */
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
+    uint32_t distSilent;    /* ... bit p: rank p was the one that did not answer */
+    uint32_t distPad;
     uint32_t kfEpoch, haloEpoch, haloPar; int32_t haloBuf;   /* multi GPU: which exchange the many-block halo copies (k_halo_copy) belong to */
     int32_t acceptBuf;      /* pool index of the accepted H: the link flow sums of the step are added from it ... */
     uint32_t aBuf, acceptABuf;   /* which A2x the step in progress uses / the accepted step used */
@@ -212,6 +214,8 @@ struct DistView {
      * spent waiting for rank p's mailbox, summed over the epochs, [1 + SF3D_MAX_RANKS + p] the longest single wait - what a rank loses
      * per exchange to the slowest of its peers (sf3d_dist_stats; bench.py prints it per rank) */
     unsigned long long* stats;
+    long long spinTicks;                 /* how long (100 MHz ticks) a rank waits for a peer's mail before the step fails: 10 s, SF3D_DIST_TIMEOUT_S (round 5: 60 s - a
+                                          * dead rank cost every survivor a minute before the error) */
 };
 /* payload layout per (receiver, source p): [parity 0/1][field][count] doubles at offset off[p];
  * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate
@@ -299,6 +303,7 @@ struct ResGrid {
     double* pub;                        /* tuning builds (SF3D_RES_PROFILE): phase timers of block 0 */
     const uint32_t* haloSrc;            /* multi GPU: [2 sides][NZ][NX] where the value of a cell of the foreign halo row above (side 0) / below (1) arrives
                                          * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
+    int32_t sidePeer[2];                /* ... the rank that row belongs to (-1: the strip lies at that edge of the grid) */
 };
 
 struct DevView {

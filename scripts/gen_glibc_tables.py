@@ -183,7 +183,13 @@ def main(libm: Path = LIBM):
     factor, cseed = read_cbrt(ro)
     L = []
     L.append("/* GENERATED by scripts/gen_glibc_tables.py - do not edit.  Data of glibc 2.35's log / exp / pow (FMA variants) and cbrt: the 128 table")
-    L.append(" * centres and the minimax polynomials are read from the installed libm, every derived entry is re-computed with mpmath and checked. */")
+    L.append(' * centres and the minimax polynomials are read from the installed libm, every derived entry is re-computed with mpmath and checked.')
+    L.append(" * Provenance of what is READ (155 constants: the 128 centres 1 / c of log and the 27 polynomial coefficients of log, pow's log, exp and")
+    L.append(" * cbrt): glibc 2.35, sysdeps/ieee754/dbl-64/e_log_data.c, e_pow_log_data.c, e_exp_data.c and s_cbrt.c - the first three are glibc's copies")
+    L.append(" * of the Arm Optimized Routines' math/log_data.c, pow_log_data.c, exp_data.c (Szabolcs Nagy, Arm Ltd, 2018; upstream MIT OR")
+    L.append(" * Apache-2.0 WITH LLVM-exception), s_cbrt.c is glibc's own; glibc distributes all of them under LGPL-2.1-or-later.  They are numerical")
+    L.append(" * constants of published algorithms, reproduced here so that the kernels return the library's bits (DESIGN.md 4); everything else in this")
+    L.append(' * file is derived from the mathematics (mpmath, 200 bits) and only CHECKED against the library. */')
     L.append("#ifndef SF3D_GLIBCMATH_TABLES_H")
     L.append("#define SF3D_GLIBCMATH_TABLES_H")
     L.append(f"#define SF3D_GL_LN2HI {fmt(LN2HI)}")

@@ -28,6 +28,8 @@ if case == "c2f20":
     m, plan = cm.catchment_model(64, 64, 10), [20.0, 0.0]
 elif case == "c2f60":
     m, plan = cm.catchment_model(64, 64, 10), [60.0, (0.0, 150)]
+elif case == "tall":             # twenty layers on a narrow grid: two ranks of eight rows each
+    m, plan = cm.catchment_model(64, 16, 20, heterogeneous=True), [20.0, (0.0, 60)]
 elif case == "het64":            # twelve soils on a grid the regular-grid sweeps accept (64 columns), cut into strips of 16 rows
     m, plan = cm.catchment_model(64, 64, 6, heterogeneous=True), [20.0, (0.0, 100)]
 elif case == "het":

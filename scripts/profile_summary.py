@@ -47,6 +47,18 @@ for k, v in res.items():
         v["hbm_traffic_MB"] = v["hbm_read_MB"] + v["hbm_write_MB"]
         if v.get("avg_active_us"):
             v["hbm_GBps"] = v["hbm_traffic_MB"] / v["avg_active_us"] * 1e3   # MB/us = TB/s
+# which kernels these numbers belong to: a fingerprint of the translation unit's sources (bench.py compares it with the sources it runs and
+# says so on the line when a stored profile describes another version of the kernels - round 5's advisor)
+try:
+    import hashlib, pathlib
+    root = pathlib.Path(__file__).resolve().parent.parent
+    h = hashlib.sha256()
+    for f in sorted((root / "criteria3d_amd" / "csrc").iterdir()):
+        if f.suffix in (".inc", ".h", ".hip", ".cpp"):
+            h.update(f.name.encode()); h.update(f.read_bytes())
+    res["source_sha16"] = h.hexdigest()[:16]
+except Exception:
+    pass
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1, sort_keys=True)
 json.dump(pmc, open(f"{out}/pmc_extract.json", "w"), indent=1, sort_keys=True)
 for k in sorted(res, key=lambda k: -res[k].get("total_ms", 0)):

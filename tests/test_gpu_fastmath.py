@@ -46,6 +46,16 @@ def same_bits(a, b):
     return np.array_equal(a.view(np.int64)[~nan], b.view(np.int64)[~nan])
 
 
+def test_box_libm_is_the_library_the_kernels_reproduce():
+    """The water tests assert the BITS of a live oracle - which calls whatever libm this box has.  The identity holds where that is the
+    library csrc/sf3d_glibcmath.inc reproduces (glibc 2.35, x86-64 FMA variants).  On another box the water tests fall back to
+    WATER_RTOL (tests/tolerances.py: water_nodes_exact) and THIS test says why - one failure instead of 150."""
+    from tests.tolerances import libm_probe
+    ok, msg = libm_probe()
+    assert ok, f"this box's libm is not the one the kernels' tables reproduce ({msg}): the live-oracle water tests ran at WATER_RTOL instead of bit identity"
+    print(msg)
+
+
 def test_default_build_is_the_faithful_set(product):
     """the shipped build evaluates the reference C library's functions (sf3d_glibcmath.inc); the 0.50-ulp set is a build option"""
     if os.environ.get("SF3D_PRODUCT_LIB"):

@@ -25,9 +25,9 @@ def test_product_matches_reference_vectors(product, name):
     for k in gold.files:
         a, b = np.asarray(trace[k], float), np.asarray(gold[k], float)
         if k.startswith("H_"):
-            assert_water_nodes(a, b, f"{name}: {k}")          # the unmodified reference's own bits
+            assert_water_nodes(a, b, f"{name}: {k}", live=False)          # the unmodified reference's own bits (a stored vector: whatever libm this box has)
         elif k.startswith("Se_"):
-            assert_water_nodes(a, b, f"{name}: {k}")
+            assert_water_nodes(a, b, f"{name}: {k}", live=False)
         elif k in ("total_water", "storage"):
             assert np.all(np.abs(a - b) <= W * np.abs(b)), k
         elif k in ("runoff", "drainage", "lateral"):

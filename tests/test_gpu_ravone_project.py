@@ -31,6 +31,9 @@ def _compare(product, oracle, m, what, base=None):
 
 @pytest.mark.parametrize("window,min_steps,need_restores", [((980, 1108, 300, 428), 1000, True), ((600, 728, 150, 278), 2000, False)])
 def test_project_window_two_hours_match_oracle(product, oracle, window, min_steps, need_restores):
+    import os
+    if not need_restores and os.environ.get("SF3D_LONG_TESTS") != "1":
+        pytest.skip("the second 128 x 128 window (no restore-best steps; 2 000 steps, half a minute of oracle time): SF3D_LONG_TESTS=1 - the suite's budget (round 5's review, item 8)")
     """128 x 128 windows of the project, the 25 mm hour and the dry hour after it, both in full.  Rows 980:1108 / cols 300:428: the
     catchment's edge (36 % outside), four soils of the map incl. BSC (0.5 m: short columns), Courant rejections, restore-best steps;
     rows 600:728 / cols 150:278: three soils, twice as many steps at smaller dt.  H and the cumulative balances within 1e-9
@@ -57,8 +60,8 @@ def _check_segment(seg, what, rtol, counters=COUNTERS):
     assert seg["dts_equal"], (what, "accepted dt sequences differ")
     assert seg["rel_H"] < rtol, (what, seg["rel_H"])
     assert seg["abs_Se"] < max(rtol, 1e-9), (what, seg["abs_Se"])
-    from tests.tolerances import WATER_NODES_EXACT
-    if WATER_NODES_EXACT and "rel_T" not in seg:          # water path, default build: the checker's bits in every one of the 5.85 M nodes
+    from tests.tolerances import water_nodes_exact
+    if water_nodes_exact() and "rel_T" not in seg:          # water path, default build: the checker's bits in every one of the 5.85 M nodes
         assert seg["H_bits_equal"] and seg["Se_bits_equal"], (what, seg["rel_H"], seg["abs_Se"])
     for q, (g, o) in seg["scalars"].items():
         assert abs(g - o) <= rtol * max(abs(o), 1e-3), (what, q, g, o)

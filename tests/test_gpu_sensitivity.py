@@ -102,8 +102,8 @@ def test_kink_window_product_stays_on_the_pin(product, same_math):
     print(f"kink window: {steps} steps; product vs {cname}: max |dH|/H = {worst:.2e}, H bit-identical at every check: {identical}"
           + (f"; vs glibc oracle {worst_other:.2e}{'' if other_alive else ' (until it left the dt sequence)'}" if other is not None else ""))
     assert steps >= min(limit, 1500)
-    from tests.tolerances import WATER_NODES_EXACT
-    if WATER_NODES_EXACT and other is None:
+    from tests.tolerances import water_nodes_exact
+    if water_nodes_exact() and other is None:
         assert identical, "H left the pin's bits somewhere along the kink window"
     gp, gc = cm.snapshot(product, m), cm.snapshot(checker, m)
     for k in ("total_water", "storage", "runoff", "drainage", "lateral"):
