@@ -126,6 +126,10 @@ struct DistBlob {
     char shmName[48];              /* POSIX shared-memory object holding a second copy of the rank's window in HOST memory: the fall-back
                                     * transport when the device windows cannot be opened or do not carry device-initiated stores */
     uint64_t windowBytes;
+    uint32_t resBlocks, resCapacity; /* resident sweep loop (sf3d_resident.inc): blocks of this rank's grid (0: its strip does not fit, or the loop is off) and how many such
+                                      * blocks its GPU holds at once - the loop runs on every rank or on none (its edge rows hand over tagged records, the single
+                                      * sweeps plain values), and ranks that share a GPU must fit on it TOGETHER (persistent kernels that have to take turns
+                                      * wait for each other's time slices) */
 };
 
 /* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR
