@@ -303,6 +303,7 @@ struct ResGrid {
     double* pub;                        /* tuning builds (SF3D_RES_PROFILE): phase timers of block 0 */
     const uint32_t* haloSrc;            /* multi GPU: [2 sides][NZ][NX] where the value of a cell of the foreign halo row above (side 0) / below (1) arrives
                                          * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
+    uint32_t forceTimeout;              /* tests (SF3D_RESIDENT_FAIL_TEST): this launch gives up in its second iteration as if a wait had expired */
     int32_t sidePeer[2];                /* ... the rank that row belongs to (-1: the strip lies at that edge of the grid) */
 };
 
