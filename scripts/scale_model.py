@@ -2,8 +2,8 @@
 """Expected strong-scaling curve of the headline workload (C4 512 x 512 x 20, F20, the 6-hour episode) at N = 2, 4, 8 GPUs - written
 BEFORE any run on more than one physical GPU, so that the driver's first SCALE record has something to be read against.
 
-Inputs (all measured on ONE MI355X; strips: profiles/r05_s_bench_*.json, one box, the gather-free paired sweeps; exchange statistics:
-profiles/r05_c_bench_2ranks_shared.json):
+Inputs (all measured on ONE MI355X; strips: profiles/r06_d_bench_*.json, one box - C4E with the resident sweep loop, csrc/sf3d_resident.inc;
+exchange statistics: profiles/r06_d_bench_2ranks_shared.json):
   * T_strip(N): the episode time of one strip of C4 run as a grid of its own (bench.py --workload C4H / C4Q / C4E = one of two / four /
     eight strips; C4 itself for N = 1) - every kernel of the step at the size a rank sees, including whether the paired sweep pays there;
   * E: exchange epochs per episode (sf3d_dist_stats of a two-rank run: one per Jacobi iteration or pair half, per K / waterFlow halo,
@@ -19,7 +19,11 @@ What the model cannot know: contention of eight ranks' puts on the xGMI links (1
 GB/s), host-side jitter of eight processes polling, and whether device-initiated system-scope stores cross GPUs at all (if not, the
 host-memory windows take over at PCIe latency - epoch cost then 10-20 us).
 
-usage: python scripts/scale_model.py [profiles-dir]  -> profiles/r05_scale_model.json"""
+Round 6: at N = 8 the Jacobi iterations of an approximation run inside ONE persistent launch per rank (the resident loop); an exchange epoch there
+is a record hand-off between running kernels, not a kernel boundary plus a last-block mailbox round - the same assumed costs are applied to it
+(pessimistic), and the k_sweep_bnd launches of the paired pass do not exist at N = 8.
+
+usage: python scripts/scale_model.py [profiles-dir]  -> profiles/r06_scale_model.json"""
 import json
 import sys
 from pathlib import Path
@@ -32,9 +36,9 @@ def line(name):
     return json.loads((prof / name).read_text().strip().splitlines()[-1])
 
 
-base = line("r05_s_bench_C4.json")
-strips = {1: base, 2: line("r05_s_bench_C4H.json"), 4: line("r05_s_bench_C4Q.json"), 8: line("r05_s_bench_C4E.json")}
-two = line("r05_c_bench_2ranks_shared.json")
+base = line("r06_d_bench_C4.json")
+strips = {1: base, 2: line("r06_d_bench_C4H.json"), 4: line("r06_d_bench_C4Q.json"), 8: line("r06_d_bench_C4E.json")}
+two = line("r06_d_bench_2ranks_shared.json")
 E = two["exchange"]["epochs"]                       # per 6-hour episode
 work = base["roofline"]["step"]["work"]
 pairs = base["roofline"]["kernels"]["k_sweep_pair"]["launches"] if "k_sweep_pair" in base["roofline"]["kernels"] else 0
@@ -42,12 +46,12 @@ LAUNCH_US = 5.0                                     # a small extra launch insid
 out = {"workload": "C4 512x512x20, F20, 6-hour episode (bench.py default)", "exchange_epochs_per_episode": E,
        "same_die_measurements": {"flag_hop_us": two["exchange"]["hop_us"], "mean_wait_per_epoch_us": two["exchange"]["mean_wait_us"],
                                  "two_ranks_sharing_one_gpu_sim_h_per_s": two["value"]},
-       "inputs": {str(n): {"strip_as_own_grid_sim_h_per_s": s["value"], "episode_ms": 6 * s["ms_per_step"], "dominant_kernel": s["roofline"]["kernel"],
+       "inputs": {str(n): {"strip_as_own_grid_sim_h_per_s": s["value"], "episode_ms": 6e3 / s["value"], "dominant_kernel": s["roofline"]["kernel"],
                            "dominant_kernel_avg_us": s["roofline"]["avg_us"]} for n, s in strips.items()},
        "assumed_epoch_cost_us": [2.0, 5.0, 10.0], "predicted": {}}
-t1 = 6 * strips[1]["ms_per_step"]
+t1 = 6e3 / strips[1]["value"]          # (`value` = 6 h / median episode; ms_per_step is the measured K-hour figure since round 6)
 for n in (2, 4, 8):
-    ts = 6 * strips[n]["ms_per_step"]
+    ts = 6e3 / strips[n]["value"]
     paired = strips[n]["roofline"]["kernel"] == "k_sweep_pair"
     # extra launches of a strip: k_sweep_bnd per paired pass (half the sweeps), two halo copies per approximation
     extra = (work["sweeps"] / 2 if paired else 0) + 2 * work["approximations"]
@@ -56,5 +60,5 @@ for n in (2, 4, 8):
         t = ts + (E * e + extra * LAUNCH_US) / 1e3
         row[f"epoch_{e:g}us"] = {"episode_ms": t, "sim_h_per_s": 6e3 / t, "speedup": t1 / t, "efficiency": t1 / t / n}
     out["predicted"][str(n)] = row
-(prof / "r05_scale_model.json").write_text(json.dumps(out, indent=1))
+(prof / "r06_scale_model.json").write_text(json.dumps(out, indent=1))
 print(json.dumps(out["predicted"], indent=1))
