@@ -61,7 +61,7 @@ except Exception:
     pass
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1, sort_keys=True)
 json.dump(pmc, open(f"{out}/pmc_extract.json", "w"), indent=1, sort_keys=True)
-for k in sorted(res, key=lambda k: -res[k].get("total_ms", 0)):
+for k in sorted((k for k in res if isinstance(res[k], dict)), key=lambda k: -res[k].get("total_ms", 0)):
     v = res[k]
     if k == "whole_run":
         print("whole run:", v); continue

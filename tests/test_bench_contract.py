@@ -17,7 +17,20 @@ def test_committed_bench_line_has_every_contract_field():
     assert line["metric"].startswith("simulated-hours/sec on 512x512x20") and line["unit"] == "sim-h/s"
     assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["vs_baseline"] is None
     assert line["dtype"] == "f64" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
-    assert abs(line["value"] - line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]
+    if Path(files[-1]).name >= "r06":
+        # round 6 on: `ms_per_step` is the MEASURED figure (the K timed hours over their time, median repetition) - `value` stays the 6-hour episode;
+        # the line carries its own parity evidence and the other BASELINE configs (config 5 water / + heat, config 3 F60) timed on the same box
+        assert abs(line["ms_per_step"] - line["timed_region"]["elapsed_s"] / line["steps"] * 1e3) < 1e-9 * line["ms_per_step"]
+        assert "bit-identical" in line["parity"]["c2_f20_hour0_vs_reference_vector"]
+        legs = line["legs"]
+        for name, nodes in (("c5_hour0", 5845035), ("c5_heat_hour0", 5845035), ("c3_f60_2h", 983040)):
+            leg = legs[name]
+            assert leg["unit"] == "sim-h/s" and leg["value"] > 0 and leg["nodes"] == nodes and leg["work"]["accepted"] > 0, name
+            assert leg["dominant_kernel"]["avg_us"] > 0 and 0 < leg["dominant_kernel"]["frac"] <= 1 and 0 < leg["step"]["frac"] <= 1, name
+        assert legs["c5_heat_hour0"]["step"]["heat_work"]["accepted"] > legs["c5_heat_hour0"]["work"]["accepted"]      # several heat sub-steps per water step
+        assert line["roofline"]["traffic_is_of_this_build"] is True      # the stored PMC profile was taken on the kernel sources of this line's build
+    else:
+        assert abs(line["value"] - line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) < 1e-6 * line["value"]
     r = line["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -141,7 +154,11 @@ def test_bench_spawns_its_own_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
     assert len(line["repeats_s"]) == 2 and min(line["repeats_s"]) > 0          # --reps 2: rewound, not rebuilt, and checked to do the same work
-    assert line["headline_6h"]["value"] == line["value"] and abs(line["value"] * line["ms_per_step"] - 1e3) < 1e-6      # `value` IS the 6-hour episode
+    assert line["headline_6h"]["value"] == line["value"]      # `value` IS the 6-hour episode ...
+    assert abs(line["ms_per_step"] - line["timed_region"]["elapsed_s"] / 6 * 1e3) < 1e-9 * line["ms_per_step"]      # ... `ms_per_step` the measured hours (round 6)
+    # an N > 1 line validates itself: the reference's vector in two strips, and the parity keys travel on the line
+    assert "2 strips" in line["parity"]["c2_f20_hour0_vs_reference_vector"] and line["exchange"]["parity"] == line["parity"]
+    assert "parity ok: C2 F20 hour 0 in 2 strip(s)" in p.stderr
     assert line["timed_region"]["hours"] == 6 and line["roofline"]["step"]["region"].startswith("one 6-hour episode")
     assert 0 < line["inclusive_value"] <= line["value"] * 1.02
     assert line["config"]["work"]["accepted"] == 50          # C2 F20: 22 + 13 + 6 + 3 + 3 + 3
@@ -190,7 +207,7 @@ def test_bench_does_not_turn_a_failed_exchange_into_a_headline():
     assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "INDEPENDENT REPLICAS" in line["config"]["partition"]
-    assert abs(line["value"] - 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]          # two hours over one replica's time
+    assert abs(line["value"] - 2 / (line["ms_per_step"] * 2 / 1e3)) < 1e-6 * line["value"]          # two hours over one replica's time (K < 6: `value` is the K hours over their time)
     assert abs(line["replica_throughput"] - 2 * line["value"]) < 1e-9 * line["value"]
     assert line["config"]["work"]["accepted"] == 22 + 13
 
