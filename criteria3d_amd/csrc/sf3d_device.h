@@ -206,8 +206,8 @@ struct DistView {
      * ncclRecv of packed buffers and the partial sums as an ncclAllGather, all queued by the host between the kernels (the form
      * SURVEY.md 8e sketches); the decision kernels then combine `gathered` in rank order exactly like the window mailboxes */
     int32_t rccl;
-    double* mine;                        /* [3] this rank's partial sums (k_local_reduce) */
-    const double* gathered;              /* [world][3] after ncclAllGather */
+    double* mine;                        /* [4] this rank's partial sums (k_local_reduce) */
+    const double* gathered;              /* [world][4] after ncclAllGather */
     double* sendBuf[SF3D_MAX_RANKS];     /* per peer: [2 fields][sendCount] packed halo values */
     const double* recvBuf[SF3D_MAX_RANKS];
     /* wait statistics of the window exchange (device memory of this rank, zeroed at connect): [0] epochs closed, [1 + p] ticks (100 MHz)
@@ -300,6 +300,8 @@ struct ResGrid {
     unsigned long long* rec;            /* [2 parities][2 halves][N] the new iterate as tagged records (a double = two words {32 data bits, 32-bit tag}) */
     unsigned long long* prec;           /* [2][4][blocks] the blocks' partial norms ((hi, lo) x two halves) */
     unsigned long long* gpub;           /* [2][4] multi GPU: the all-gathered norm, published by block 0 */
+    unsigned long long* prec2;          /* [8][blocks] the blocks' sums of the mass balance (the fused post-solve part: storage and sink term, double-doubles, two halves each) */
+    uint32_t fusedPost;                 /* 1: the loop's launch also does k_post's work when the solve ends well (SF3D_RESIDENT_POST=0: k_post stays a launch of its own) */
     double* pub;                        /* tuning builds (SF3D_RES_PROFILE): phase timers of block 0 */
     const uint32_t* haloSrc;            /* multi GPU: [2 sides][NZ][NX] where the value of a cell of the foreign halo row above (side 0) / below (1) arrives
                                          * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
