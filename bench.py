@@ -777,7 +777,7 @@ def main():
         note = None
         if dom == "k_sweep_resident":
             note = ("one launch = ALL Jacobi iterations of an approximation with the rows resident in registers (csrc/sf3d_resident.inc): bound by the "
-                    "grid barrier between iterations (latency), not by bytes - `frac` prices the little it still moves")
+                    "record hand-over between iterations (latency), not by bytes - `frac` prices the little it still moves")
         if dom == "k_sweep_pair":
             note = ("one pass = two Jacobi iterations: `frac` prices the 160 B/node the pass moves; `equivalent_sweep_frac` prices the two "
                     "single sweeps it replaces (2 x 152 B/node, SURVEY 8d) and is a speed-up measure, not a bandwidth fraction")
