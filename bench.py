@@ -425,6 +425,30 @@ def main():
                 ok, parity_msg = reference_vector_check(sf, cm, rank, world, allgather_bytes)
             except Exception as e:  # noqa: BLE001
                 ok, parity_msg = False, f"the run itself failed: {e}"
+        if not fails and os.environ.get("SF3D_PAIR_RECORDS") != "0":
+            # ... and of the paired pass's record hand-over (strips too large for the resident loop - C4 on 2 or 4 GPUs - run it; C2's
+            # strips would take the resident loop): the same vector once more with the paired pass forced.  A failure turns the hand-over
+            # off on every rank (two launches and two plain exchanges per pass), loudly and on the line
+            forced = {"SF3D_RESIDENT_SWEEP": "0", "SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6"}
+            saved = {k: os.environ.get(k) for k in forced}
+            os.environ.update(forced)
+            try:
+                ok2, msg2 = reference_vector_check(sf, cm, rank, world, allgather_bytes)
+            except Exception as e:  # noqa: BLE001
+                ok2, msg2 = False, f"the run itself failed: {e}"
+            for k, val in saved.items():
+                if val is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = val
+            fails2 = [x.decode() for x in allgather_bytes(b"" if ok2 else f"rank {rank}: {msg2}".encode()) if x]
+            if fails2:
+                first_contact = "paired pass: record hand-over disabled after a failed first contact: " + "; ".join(fails2)[:600]
+                log(f"[bench] rank {rank}: {first_contact}")
+                os.environ["SF3D_PAIR_RECORDS"] = "0"
+                sf.lib.sf3d_clean()
+            else:
+                log(f"[bench] rank {rank}: paired pass with record hand-over: {msg2}")
     log(f"[bench] rank {rank}: {'parity ok' if ok else 'PARITY FAILURE'}: {parity_msg}")
     if world > 1:
         ok = all(x == b"1" for x in allgather_bytes(b"1" if ok else b"0"))

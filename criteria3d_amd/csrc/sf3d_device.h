@@ -118,7 +118,7 @@ struct Ctrl {
     uint32_t epoch;         /* exchange counter, identical on every rank (multi-GPU) */
     uint32_t distError;     /* 1 = a bounded wait for a peer expired */
     uint32_t distSilent;    /* ... bit p: rank p was the one that did not answer */
-    uint32_t distPad;
+    uint32_t pairRecTimeout; /* 1: a block of a paired pass waited longer than the bound for a neighbouring strip's record (PairGrid::records) */
     uint32_t kfEpoch, haloEpoch, haloPar; int32_t haloBuf;   /* multi GPU: which exchange the many-block halo copies (k_halo_copy) belong to */
     int32_t acceptBuf;      /* pool index of the accepted H: the link flow sums of the step are added from it ... */
     uint32_t aBuf, acceptABuf;   /* which A2x the step in progress uses / the accepted step used */
@@ -149,7 +149,8 @@ struct Ctrl {
     double cgRho, cgAlpha, cgBeta, cgBnorm2, cgRes2;
     uint32_t seqCount, seqSweeps[16];   /* Jacobi iterations of the 1st, 2nd, ... approximation of the computeStep in progress (0 for one the Courant check
                                           * refused): the host queues that many sweeps (+1) for the same approximation of the NEXT step */
-    uint32_t barGen;          /* (unused) */
+    uint32_t haloLocalTag;    /* paired pass with record hand-over ended by its FIRST decision: epoch + 1 of that moment - the halo of H = x' is in the X pool
+                               * already (the blocks that waited for the records stored them), k_post must not arm the copy from the window */
     uint32_t barTimeout;      /* 1: a block waited longer than the bound at a grid barrier (blocks not co-resident?): the step failed */
     uint64_t residentLaunches;  /* k_sweep_resident launches that really ran (one per approximation: all its Jacobi iterations) */
     /* paired sweep on a strip (multi GPU): k_sweep_pair leaves the second iteration of the rows next to a neighbouring strip to
@@ -202,6 +203,8 @@ struct DistView {
     /* [10][N]: where the value of a FOREIGN neighbour arrives in my window (SF3D_FSRC_NONE for local neighbours); read only
      * in chunks whose descriptor is flagged (ChunkDesc::pad0): the sweeps take foreign neighbours straight from the payload */
     const uint32_t* fsrc;
+    const uint32_t* hsrc;               /* [N] where the value of a local node that belongs to another rank arrives in my window: (rank << 27) | position in its
+                                         * send list; SF3D_FSRC_NONE for my own nodes (paired pass with record hand-over; null otherwise) */
     /* SF3D_EXCHANGE=rccl (or the automatic fall-back when the windows fail their self-check): halos travel as paired ncclSend /
      * ncclRecv of packed buffers and the partial sums as an ncclAllGather, all queued by the host between the kernels (the form
      * SURVEY.md 8e sketches); the decision kernels then combine `gathered` in rank order exactly like the window mailboxes */
@@ -278,6 +281,15 @@ struct PairGrid {
     const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
     const uint32_t* patchList;          /* [blocks] patches that hold nodes: (band of W - 2 rows << 12) | first column (NX <= 4096; else column / 64) */
     const uint8_t* patchDepth;          /* [blocks] layers the patch (halo included) reaches */
+    uint32_t records;                   /* multi GPU: 1 = ONE launch and ONE exchange per pass - the first iterate of a neighbouring strip's row arrives as tagged
+                                         * records (DF_RECLO / DF_RECHI) while the pass runs, the blocks whose ring holds such a row wait for them layer by
+                                         * layer, every owned row gets both iterations here and k_sweep_bnd is not launched (sf3d_pair.inc, DIST) */
+    /* ... on a regular grid the records of an edge row sit in the neighbour's window at (layer) * stride + column from a base - the host checks the
+     * send and receive lists for it - so that neither side looks anything up between computing a value and storing it, or before polling */
+    uint32_t recFast;                   /* 1: the five fields below hold */
+    int32_t sidePeer[2];                /* the rank above (side 0) / below (1) the strip; -1 at an edge of the grid */
+    uint32_t putBase[2], getBase[2];    /* position of (layer 0, column 0) of my edge row in that rank's send list / of its edge row (my halo row) in my receive list */
+    uint32_t recStride;                 /* positions per layer (the same in all four lists: NX) */
     const uint8_t* role;                /* [N] multi GPU (masked grids): 0 = another rank's node (halo: never computed here), 1 = mine, both iterations in
                                          * k_sweep_pair_masked, 2 = mine in a chunk that reads a neighbouring strip (ChunkDesc::pad0): first iteration +
                                          * put there, second iteration in k_sweep_bnd.  null on one GPU */

@@ -130,6 +130,8 @@ struct DistBlob {
                                       * blocks its GPU holds at once - the loop runs on every rank or on none (its edge rows hand over tagged records, the single
                                       * sweeps plain values), and ranks that share a GPU must fit on it TOGETHER (persistent kernels that have to take turns
                                       * wait for each other's time slices) */
+    uint32_t pairRecords, pairPad;   /* paired pass with record hand-over (sf3d_pair.inc, DIST): nonzero = this rank runs the paired pass and hands its edge rows over as
+                                      * records - used only if EVERY rank says so (a rank on single sweeps puts plain values and needs two exchanges per two iterations) */
 };
 
 /* The device half.  All methods return an sf3d_error_t; HIP failures map to SF3D_SOLVER_ERROR

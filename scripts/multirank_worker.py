@@ -99,6 +99,10 @@ res["host_bytes_end"] = np.array(int(sf.lib.sf3d_host_bytes()), dtype=np.int64)
 c = sf.counters()
 res["counters"] = np.array([c[k] for k in capi.COUNTER_NAMES[:7]], dtype=np.int64)
 res["sweep_launches"] = np.array(sf.sweep_launches() + (sf.resident_launches(),), dtype=np.int64)          # (single sweeps, paired passes, resident loops) of this rank
+try:
+    res["epochs"] = np.array(sf.dist_stats(world)["epochs"], dtype=np.int64)      # exchange epochs (mailbox rounds) of the whole run
+except Exception:
+    res["epochs"] = np.array(-1, dtype=np.int64)
 np.savez(outfile, **res)
 dist.barrier()
 sf.lib.sf3d_clean()

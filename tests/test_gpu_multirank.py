@@ -25,7 +25,9 @@ def _run_ranks_once(world, case, tmp_path, port, env):
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), str(world),
                                        str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                                      env=dict(os.environ, SF3D_DIST_VERBOSE="1", SF3D_DIST_TIMEOUT_S=os.environ.get("SF3D_DIST_TIMEOUT_S", "60"), **(env or {}))))      # (ranks taking turns on one GPU: the exchange's 10 s bound is for ranks with a GPU each)
+                                      env={**os.environ, "SF3D_DIST_VERBOSE": "1", "SF3D_DIST_TIMEOUT_S": os.environ.get("SF3D_DIST_TIMEOUT_S", "60"),      # (ranks taking turns on one GPU: the exchange's 10 s bound is for ranks with a GPU each)
+                                           "SF3D_PAIR_RECORDS": "1",      # the paired pass hands its edge rows over as records although the ranks share the box's GPU (the product's default with a GPU per rank)
+                                           **(env or {})}))
     logs = []
     for p in procs:
         try:
@@ -145,15 +147,24 @@ def test_paired_sweep_on_strips_is_bitwise_the_single_sweeps(tmp_path, world, ca
     owned node's H and Se, every accepted dt and every work counter equal to the run with single sweeps; paired passes on every rank"""
     pair = run_ranks(world, case, tmp_path, port, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6", "SF3D_DIST_LOCAL": local})
     single = run_ranks(world, case, tmp_path, port + 1, env={"SF3D_PAIR_SWEEP": "0", "SF3D_RESIDENT_SWEEP": "0", "SF3D_DIST_LOCAL": local})
+    runs = [pair]
+    if (case, local) in (("c2f60", "1"), ("holes", "1")):
+        # the default pass hands the edge rows' first iterate over as tagged records while it runs (one launch, ONE exchange per pass);
+        # SF3D_PAIR_RECORDS=0 is the two-launch form (k_sweep_bnd, two exchanges per pass): same bits, more mailbox rounds
+        plain = run_ranks(world, case, tmp_path, port + 40, env={"SF3D_PAIR_SWEEP": "1", "SF3D_PAIR_W": "6", "SF3D_DIST_LOCAL": local, "SF3D_PAIR_RECORDS": "0"})
+        runs.append(plain)
+        e_rec, e_plain, passes = int(pair[0]["epochs"]), int(plain[0]["epochs"]), int(pair[0]["sweep_launches"][1])
+        assert e_rec > 0 and 0 < e_plain - e_rec <= passes, (e_rec, e_plain, passes)      # one exchange less per pass that did not end on its first iterate
     owner = pair[0]["owner"]
-    for r in range(world):
-        assert int(pair[r]["sweep_launches"][1]) > 0 and int(single[r]["sweep_launches"][1]) == 0, (r, pair[r]["sweep_launches"])
-        mine = owner == r
-        for k in pair[r].files:
-            if k.startswith(("H_h", "Se_h")):
-                assert np.array_equal(pair[r][k][mine], single[r][k][mine]), (r, k)
-            elif k.startswith("dts_h") or k == "counters":
-                assert np.array_equal(pair[r][k], single[r][k]), (r, k)
+    for run in runs:
+        for r in range(world):
+            assert int(run[r]["sweep_launches"][1]) > 0 and int(single[r]["sweep_launches"][1]) == 0, (r, run[r]["sweep_launches"])
+            mine = owner == r
+            for k in run[r].files:
+                if k.startswith(("H_h", "Se_h")):
+                    assert np.array_equal(run[r][k][mine], single[r][k][mine]), (r, k)
+                elif k.startswith("dts_h") or k == "counters":
+                    assert np.array_equal(run[r][k], single[r][k]), (r, k)
 
 
 @pytest.mark.parametrize("world,case,port,local", [(2, "c2f20", 29671, "1"), (4, "c2f60", 29673, "1"), (2, "c2f60", 29675, "0"), (4, "het64", 29677, "1"),
