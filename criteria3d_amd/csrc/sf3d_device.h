@@ -186,6 +186,11 @@ struct DistWindow {                     /* head of each rank's window; payload d
     DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
     unsigned long long ping[SF3D_MAX_RANKS];   /* start-up self-check: peer p stores a token here through its mapping of this window */
 };
+/* record hand-over of the masked paired pass, per node (one load instead of a walk through the chunk's send list / a look-up chain):
+ * where a foreign local node's record arrives in my window, and where an owned node's record goes in its reader's window - positions in
+ * doubles from the window's payload, parity 0, field DF_RECLO; parity 1 lies SF3D_DIST_FIELDS * cnt further, DF_RECHI cnt further */
+struct RecGet { uint32_t off0, cnt; };                        /* off0 = SF3D_FSRC_NONE: the node is mine */
+struct RecPut { uint32_t off0, cnt, peer, nDest; };           /* nDest: readers of the node (0: none, 1: the entry describes it, 2+: walk the list) */
 struct DistView {
     int32_t world, rank;
     DistWindow* win[SF3D_MAX_RANKS];    /* win[rank] = own window (local pointer), others IPC-mapped */
@@ -203,6 +208,7 @@ struct DistView {
     /* [10][N]: where the value of a FOREIGN neighbour arrives in my window (SF3D_FSRC_NONE for local neighbours); read only
      * in chunks whose descriptor is flagged (ChunkDesc::pad0): the sweeps take foreign neighbours straight from the payload */
     const uint32_t* fsrc;
+    const RecGet* recGet; const RecPut* recPut;      /* [N] each (masked paired pass with record hand-over; null otherwise) */
     const uint32_t* hsrc;               /* [N] where the value of a local node that belongs to another rank arrives in my window: (rank << 27) | position in its
                                          * send list; SF3D_FSRC_NONE for my own nodes (paired pass with record hand-over; null otherwise) */
     /* SF3D_EXCHANGE=rccl (or the automatic fall-back when the windows fail their self-check): halos travel as paired ncclSend /
