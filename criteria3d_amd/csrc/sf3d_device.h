@@ -325,6 +325,8 @@ struct ResGrid {
                                          * in my window ((source rank << 27) | position in its send list; SF3D_FSRC_NONE: no such row) */
     uint32_t forceTimeout;              /* tests (SF3D_RESIDENT_FAIL_TEST): this launch gives up in its second iteration as if a wait had expired */
     int32_t sidePeer[2];                /* ... the rank that row belongs to (-1: the strip lies at that edge of the grid) */
+    uint32_t recFast, putBase[2];       /* 1: my edge row's cells lie at putBase[side] + layer * NX + column in that rank's send list (sf3d_host_build.inc
+                                         * edge_rows_direct): the records are stored without a walk through the chunk's send list */
 };
 
 struct DevView {
