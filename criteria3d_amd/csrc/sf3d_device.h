@@ -185,6 +185,9 @@ struct DistMail { unsigned long long seq; double v[4]; };      /* (four: both no
 struct DistWindow {                     /* head of each rank's window; payload doubles follow */
     DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
     unsigned long long ping[SF3D_MAX_RANKS];   /* start-up self-check: peer p stores a token here through its mapping of this window */
+    unsigned long long rrec[2][SF3D_MAX_RANKS][4];   /* [epoch parity][source rank]: that rank's partial norm of a resident-loop iteration as tagged records
+                                                       * ((hi, lo) of a double-double, two words each; tag = epoch + 1): every block of every rank reads them
+                                                       * here and adds them in rank order - no mailbox round, no fence, no second hand-over inside the rank */
 };
 /* record hand-over of the masked paired pass, per node (one load instead of a walk through the chunk's send list / a look-up chain):
  * where a foreign local node's record arrives in my window, and where an owned node's record goes in its reader's window - positions in
