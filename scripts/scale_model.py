@@ -21,7 +21,9 @@ host-memory windows take over at PCIe latency - epoch cost then 10-20 us).
 
 Round 6: at N = 8 the Jacobi iterations of an approximation run inside ONE persistent launch per rank (the resident loop); an exchange epoch there
 is a record hand-off between running kernels, not a kernel boundary plus a last-block mailbox round - the same assumed costs are applied to it
-(pessimistic), and the k_sweep_bnd launches of the paired pass do not exist at N = 8.
+(pessimistic), and the k_sweep_bnd launches of the paired pass do not exist at N = 8.  At N = 2 / 4 the paired pass hands its edge rows over as
+records while it runs (sf3d_pair.inc, DIST "record hand-over"): no k_sweep_bnd launch and ONE exchange epoch per pass - E minus the passes of an
+episode (309: 5 511 against 3 966 mailbox rounds over five episodes, profiles/r06_i_record_handover_on_strips_ab.txt).
 
 usage: python scripts/scale_model.py [profiles-dir]  -> profiles/r06_scale_model.json"""
 import json
@@ -37,7 +39,8 @@ def line(name):
 
 
 base = line("r06_d_bench_C4.json")
-strips = {1: base, 2: line("r06_d_bench_C4H.json"), 4: line("r06_d_bench_C4Q.json"), 8: line("r06_d_bench_C4E.json")}
+strips = {1: base, 2: line("r06_d_bench_C4H.json"), 4: line("r06_d_bench_C4Q.json"), 8: line("r06_z_bench_C4E.json")}      # (C4E: the final kernels, post-solve part fused)
+PASSES = 309                                        # paired passes per episode = exchange epochs the record hand-over saves (see above)
 two = line("r06_d_bench_2ranks_shared.json")
 E = two["exchange"]["epochs"]                       # per 6-hour episode
 work = base["roofline"]["step"]["work"]
@@ -53,11 +56,12 @@ t1 = 6e3 / strips[1]["value"]          # (`value` = 6 h / median episode; ms_per
 for n in (2, 4, 8):
     ts = 6e3 / strips[n]["value"]
     paired = strips[n]["roofline"]["kernel"] == "k_sweep_pair"
-    # extra launches of a strip: k_sweep_bnd per paired pass (half the sweeps), two halo copies per approximation
-    extra = (work["sweeps"] / 2 if paired else 0) + 2 * work["approximations"]
-    row = {"compute_only_sim_h_per_s": 6e3 / ts, "compute_only_speedup": t1 / ts}
+    # extra launches of a strip: two halo copies per approximation (rounds 3-5 also: k_sweep_bnd per paired pass); epochs: one per pass with the hand-over
+    extra = 2 * work["approximations"]
+    En = E - PASSES if paired else E
+    row = {"compute_only_sim_h_per_s": 6e3 / ts, "compute_only_speedup": t1 / ts, "exchange_epochs": En}
     for e in out["assumed_epoch_cost_us"]:
-        t = ts + (E * e + extra * LAUNCH_US) / 1e3
+        t = ts + (En * e + extra * LAUNCH_US) / 1e3
         row[f"epoch_{e:g}us"] = {"episode_ms": t, "sim_h_per_s": 6e3 / t, "speedup": t1 / t, "efficiency": t1 / t / n}
     out["predicted"][str(n)] = row
 (prof / "r06_scale_model.json").write_text(json.dumps(out, indent=1))
