@@ -212,8 +212,6 @@ struct DistView {
      * in chunks whose descriptor is flagged (ChunkDesc::pad0): the sweeps take foreign neighbours straight from the payload */
     const uint32_t* fsrc;
     const RecGet* recGet; const RecPut* recPut;      /* [N] each (masked paired pass with record hand-over; null otherwise) */
-    const uint32_t* hsrc;               /* [N] where the value of a local node that belongs to another rank arrives in my window: (rank << 27) | position in its
-                                         * send list; SF3D_FSRC_NONE for my own nodes (paired pass with record hand-over; null otherwise) */
     /* SF3D_EXCHANGE=rccl (or the automatic fall-back when the windows fail their self-check): halos travel as paired ncclSend /
      * ncclRecv of packed buffers and the partial sums as an ncclAllGather, all queued by the host between the kernels (the form
      * SURVEY.md 8e sketches); the decision kernels then combine `gathered` in rank order exactly like the window mailboxes */

@@ -26,7 +26,6 @@ def _run_ranks_once(world, case, tmp_path, port, env):
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "scripts" / "multirank_worker.py"), str(r), str(world),
                                        str(port), case, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                       env={**os.environ, "SF3D_DIST_VERBOSE": "1", "SF3D_DIST_TIMEOUT_S": os.environ.get("SF3D_DIST_TIMEOUT_S", "60"),      # (ranks taking turns on one GPU: the exchange's 10 s bound is for ranks with a GPU each)
-                                           "SF3D_PAIR_RECORDS": "1",      # the paired pass hands its edge rows over as records although the ranks share the box's GPU (the product's default with a GPU per rank)
                                            **(env or {})}))
     logs = []
     for p in procs:
