@@ -231,8 +231,8 @@ struct DistView {
  * field 0 = the iterate of a sweep (x of the water system / T of the heat system), 1 = K, 2 = waterFlow.  Separate
  * fields because the x of the LAST sweep of an approximation is consumed late (by the readers' k_post), after a fast
  * neighbour may already have put the K of the next approximation into the same parity. */
-#define SF3D_DIST_FIELDS 5
-enum { DF_X = 0, DF_K = 1, DF_FLOW = 2, DF_RECLO = 3, DF_RECHI = 4 };      /* (3, 4: the iterate as tagged records, for the resident sweep loop's in-launch hand-off - sf3d_resident.inc) */
+#define SF3D_DIST_FIELDS 9
+enum { DF_X = 0, DF_K = 1, DF_FLOW = 2, DF_RECLO = 3, DF_RECHI = 4, DF_KLO = 5, DF_KHI = 6, DF_FLO = 7, DF_FHI = 8 };      /* (3, 4: the iterate as tagged records, for the resident sweep loop's in-launch hand-off - sf3d_resident.inc) */
 #define SF3D_FSRC_NONE 0xFFFFFFFFu      /* fsrc: (source rank << 27) | position in that rank's send list */
 
 /* coupled heat transport (heat.cpp): everything the heat kernels and the heat terms of the water kernels

@@ -23,7 +23,9 @@ Round 6: at N = 8 the Jacobi iterations of an approximation run inside ONE persi
 is a record hand-off between running kernels, not a kernel boundary plus a last-block mailbox round - the same assumed costs are applied to it
 (pessimistic), and the k_sweep_bnd launches of the paired pass do not exist at N = 8.  At N = 2 / 4 the paired pass hands its edge rows over as
 records while it runs (sf3d_pair.inc, DIST "record hand-over"): no k_sweep_bnd launch and ONE exchange epoch per pass - E minus the passes of an
-episode (309: 5 511 against 3 966 mailbox rounds over five episodes, profiles/r06_i_record_handover_on_strips_ab.txt).
+episode (309: 5 511 against 3 966 mailbox rounds over five episodes, profiles/r06_i_record_handover_on_strips_ab.txt).  At every N the halos of
+K and waterFlow are tagged records the reader's copy kernel waits for - no barrier across the ranks behind k_props<2>: one epoch per
+approximation less than the two-rank line of job 10 counted (1 103 -> 970).
 
 usage: python scripts/scale_model.py [profiles-dir]  -> profiles/r06_scale_model.json"""
 import json
@@ -44,6 +46,7 @@ PASSES = 309                                        # paired passes per episode 
 two = line("r06_d_bench_2ranks_shared.json")
 E = two["exchange"]["epochs"]                       # per 6-hour episode
 work = base["roofline"]["step"]["work"]
+E -= work["approximations"]                         # K / waterFlow halos travel as tagged records: no barrier behind k_props<2> (5 511 -> 4 846 rounds over five episodes, job 35)
 pairs = base["roofline"]["kernels"]["k_sweep_pair"]["launches"] if "k_sweep_pair" in base["roofline"]["kernels"] else 0
 LAUNCH_US = 5.0                                     # a small extra launch inside a replayed graph (profiles/r03_barrier_probe.txt: 1.7-2.7 us boundary + a few us of work)
 out = {"workload": "C4 512x512x20, F20, 6-hour episode (bench.py default)", "exchange_epochs_per_episode": E,
