@@ -181,7 +181,7 @@ struct Ctrl {
  * reader's own arrays by its next decision kernel, which also all-gathers the partial sums through
  * the same windows (system-scope stores + epoch-stamped flags, double-buffered by epoch parity). */
 #define SF3D_MAX_RANKS 16
-struct DistMail { unsigned long long seq; double v[4]; };      /* (four: both norms of a paired pass, each a double-double) */
+struct DistMail { unsigned long long w[8]; };      /* four values (both norms of a paired pass, each a double-double) as tagged records: (low 32 bits | tag << 32), (high 32 bits | tag << 32), tag = epoch + 1 - value and flag in one word, one round trip */
 struct DistWindow {                     /* head of each rank's window; payload doubles follow */
     DistMail mail[2][SF3D_MAX_RANKS];   /* [epoch parity][source rank] */
     unsigned long long ping[SF3D_MAX_RANKS];   /* start-up self-check: peer p stores a token here through its mapping of this window */
