@@ -42,6 +42,26 @@ def test_strips_are_row_blocks_cut_at_chunk_boundaries(product):
     product.lib.sf3d_clean()
 
 
+def test_edge_rows_of_a_regular_strip_lie_in_the_lists_as_layer_times_nx_plus_column(product):
+    """What the in-launch record hand-overs count on (sf3d_host_build.inc edge_rows_direct): on a regular grid a rank's edge row
+    lies in the neighbour's send / receive lists as base + layer * NX + column - the kernels of the paired pass and of the resident loop then
+    store and poll their records without a walk through a chunk's send list.  A change of the partition's list order would not break a
+    result (the host checks the layout and falls back to the two-launch form / the list walk), it would silently cost the speed: held here."""
+    nx, ny, nz, world = 128, 64, 5, 4
+    m = cm.catchment_model(nx, ny, nz)
+    cm.build(product, m, finalize=False)
+    ns, rows = nx * ny, ny // world
+    for r in range(world):
+        for peer, r_edge, r_halo in ((r - 1, r * rows, r * rows - 1), (r + 1, (r + 1) * rows - 1, (r + 1) * rows)):
+            if peer < 0 or peer >= world:
+                continue
+            layer, col = np.meshgrid(np.arange(nz), np.arange(nx), indexing="ij")
+            assert np.array_equal(product.halo_list(r, world, peer, 0), (layer * ns + r_edge * nx + col).ravel()), (r, peer, "send")
+            assert np.array_equal(product.halo_list(r, world, peer, 1), (layer * ns + r_halo * nx + col).ravel()), (r, peer, "receive")
+    product.lib.sf3d_clean()
+    product.check(product.lib.sf3d_dist_prepare(0, 1), "dist_prepare")
+
+
 def _models():
     from tests.scenarios import ravone_project_model
     return {"grid": lambda: cm.catchment_model(128, 48, 5), "het": lambda: cm.catchment_model(64, 40, 6, heterogeneous=True),
