@@ -287,7 +287,8 @@ struct PairGrid {
     uint32_t masked;                    /* 1: the fields below describe the graph, chunkCode is unused */
     const int32_t* idxMap;              /* [(l NY + r) NX + c] node index of the cell, -1 where there is none */
     const uint32_t* patchList;          /* [blocks] patches that hold nodes: (band of W - 2 rows << 12) | first column (NX <= 4096; else column / 64) */
-    const uint8_t* patchDepth;          /* [blocks] layers the patch (halo included) reaches */
+    const uint8_t* patchDepth;          /* [blocks] bits 0-6: layers the patch (halo included) reaches; bit 7 (multi GPU): a column of another rank lies in the patch's
+                                         * footprint - after the first pass of an approximation such blocks take those cells' old iterate from the window */
     uint32_t records;                   /* multi GPU: 1 = ONE launch and ONE exchange per pass - the first iterate of a neighbouring strip's row arrives as tagged
                                          * records (DF_RECLO / DF_RECHI) while the pass runs, the blocks whose ring holds such a row wait for them layer by
                                          * layer, every owned row gets both iterations here and k_sweep_bnd is not launched (sf3d_pair.inc, DIST) */
